@@ -1,0 +1,536 @@
+// dockauv_capi.hip -- C ABI of libdockauv.so (include/dockauv.h): handle, HBM buffers, field I/O, step launch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dockauv.h"
+#include "dockauv_device.h"
+
+using namespace dockauv;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct FieldDesc {
+    void* base;   // device base of row 0
+    int rows;     // device rows
+    int kind;     // 0 = T, 1 = int32, 2 = uint8
+};
+
+}  // namespace
+
+struct dockauv_env_s {
+    dockauv_config cfg;
+    int device = 0;
+    bool f64 = false;
+    size_t tsz = 4;
+    long S = 0;   // SoA row stride (envs rounded up to 64)
+    int n_rays = 0, n_red = 0, n_obs = 0, n_u_max = 0;
+    int vk = VK_JOY;
+    bool has_rays = false;
+    int threads = 64;
+    Buffers B{};
+    std::vector<void*> allocs;
+    KernelArgs<float, 2> a32{};
+    KernelArgs<double, 2> a64{};
+    std::string err;
+    hipStream_t last_stream = nullptr;
+    // host-pointer step staging
+    void* d_actions = nullptr;
+    void* d_noise = nullptr;
+    float* d_obs = nullptr;
+    void* d_reward = nullptr;
+    uint8_t* d_done = nullptr;
+    void* d_terms = nullptr;
+    uint8_t* d_cond = nullptr;
+    void* d_nav = nullptr;
+    void* d_raydist = nullptr;
+    float* d_termobs = nullptr;
+};
+
+namespace {
+
+int fail(dockauv_handle h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) return fail(h, DOCKAUV_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int dalloc(dockauv_handle h, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(h, DOCKAUV_E_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    e = hipMemset(*p, 0, bytes);
+    if (e != hipSuccess) return fail(h, DOCKAUV_E_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    h->allocs.push_back(*p);
+    return 0;
+}
+
+template <typename T>
+void fill_vehicle(VehicleP<T>& d, const dockauv_vehicle& v) {
+    d.m = (T)v.m;
+    d.gWB = (T)(v.W - v.BY);
+    d.gx = (T)(v.r_G[0] * v.W - v.r_B[0] * v.BY);
+    d.gy = (T)(v.r_G[1] * v.W - v.r_B[1] * v.BY);
+    d.gz = (T)(v.r_G[2] * v.W - v.r_B[2] * v.BY);
+    for (int i = 0; i < 3; ++i) d.rg[i] = (T)v.r_G[i];
+    for (int i = 0; i < 9; ++i) d.Ib[i] = (T)v.I_b[i];
+    for (int i = 0; i < 6; ++i) {
+        d.ma[i] = (T)v.ma_diag[i];
+        d.dl[i] = (T)v.d_lin[i];
+        d.dq[i] = (T)v.d_quad[i];
+    }
+    for (int i = 0; i < 36; ++i) d.Minv[i] = (T)v.M_inv[i];
+    for (int i = 0; i < 6 * kMaxU; ++i) d.B[i] = (T)v.B[i];
+    for (int i = 0; i < kMaxU; ++i) {
+        d.ulo[i] = (T)v.u_lo[i];
+        d.uhalf[i] = (T)(v.u_hi[i] - v.u_lo[i]);
+    }
+    for (int i = 0; i < L_COUNT; ++i) d.lauv[i] = (T)v.lauv[i];
+    d.n_u = v.n_u;
+}
+
+template <typename T>
+void fill_env(EnvP<T>& e, const dockauv_env_s& h) {
+    const dockauv_config& c = h.cfg;
+    e.n_envs = c.n_envs;
+    e.max_timesteps = c.max_timesteps;
+    e.reward_set = c.reward_set;
+    e.reset_mode = c.reset_mode;
+    e.scenario = c.scenario;
+    e.n_v = c.n_v;
+    e.n_h = c.n_h;
+    e.blk = c.blocksize_reduce;
+    e.n_vr = (c.n_v + c.blocksize_reduce - 1) / c.blocksize_reduce;
+    e.n_hr = (c.n_h + c.blocksize_reduce - 1) / c.blocksize_reduce;
+    e.n_rays = h.n_rays;
+    e.n_red = h.n_red;
+    e.n_obs = h.n_obs;
+    e.max_cap = c.max_capsules;
+    e.max_sph = c.max_spheres;
+    e.n_u_max = h.n_u_max;
+    e.seed = c.seed;
+    e.h = (T)c.t_step_size;
+    e.lp_alpha = (T)(c.t_step_size / (c.t_step_size + c.lowpass_T1));   // utils/lowpassfilter.py:27
+    e.mu = (T)c.current_mu;
+    e.dmax = (T)c.max_dist_from_goal;
+    e.dtol = (T)c.dist_goal_reached_tol;
+    e.max_att = (T)c.max_attitude;
+    e.safety = (T)c.safety_radius;
+    for (int i = 0; i < 6; ++i) e.vel_max[i] = (T)c.vel_max[i];
+    e.w_d = (T)c.w_d;
+    e.w_dth = (T)c.w_delta_theta;
+    e.w_dpsi = (T)c.w_delta_psi;
+    e.w_phi = (T)c.w_phi;
+    e.w_th = (T)c.w_theta;
+    e.w_thdot = (T)c.w_Thetadot;
+    e.w_oa = (T)c.w_oa;
+    for (int i = 0; i < 5; ++i) e.w_done[i] = (T)c.w_done[i];
+    for (int i = 0; i < kMaxU; ++i) e.w_act[i] = (T)c.action_reward_factors[i];
+    e.ray_max = (T)c.radar_max_dist;
+    e.alpha_max = (T)c.radar_alpha_max;
+    e.beta_max = (T)c.radar_beta_max;
+}
+
+bool b_is_diagonal(const dockauv_vehicle& v) {
+    if (v.n_u != 6) return false;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < kMaxU; ++j)
+            if (i != j && v.B[i * kMaxU + j] != 0.0) return false;
+    return true;
+}
+
+int field_info(dockauv_handle h, int field, FieldDesc* fd, int* width) {
+    const dockauv_config& c = h->cfg;
+    switch (field) {
+        case DOCKAUV_F_STATE: *fd = {h->B.state, 12, 0}; *width = 12; return 0;
+        case DOCKAUV_F_U: *fd = {h->B.u, kMaxU, 0}; *width = kMaxU; return 0;
+        case DOCKAUV_F_GOAL: *fd = {h->B.goal, 4, 0}; *width = 4; return 0;
+        case DOCKAUV_F_CURRENT: *fd = {h->B.cur, 8, 0}; *width = 5; return 0;
+        case DOCKAUV_F_TSTEPS: *fd = {h->B.t_steps, 1, 1}; *width = 1; return 0;
+        case DOCKAUV_F_CAPSULES: *fd = {h->B.caps, c.max_capsules * 7, 0}; *width = c.max_capsules * 7; return 0;
+        case DOCKAUV_F_SPHERES: *fd = {h->B.sph, c.max_spheres * 4, 0}; *width = c.max_spheres * 4; return 0;
+        case DOCKAUV_F_VEHICLE_ID: *fd = {h->B.veh_id, 1, 2}; *width = 1; return 0;
+        case DOCKAUV_F_CUM_REWARD: *fd = {h->B.cum_reward, 1, 0}; *width = 1; return 0;
+        case DOCKAUV_F_EPISODE: *fd = {h->B.episode, 1, 1}; *width = 1; return 0;
+        case DOCKAUV_F_POOL_POSE: *fd = {h->B.p_pose, 6, 0}; *width = 6; return 0;
+        case DOCKAUV_F_POOL_GOAL: *fd = {h->B.p_goal, 4, 0}; *width = 4; return 0;
+        case DOCKAUV_F_POOL_CURRENT: *fd = {h->B.p_cur, 8, 0}; *width = 5; return 0;
+        case DOCKAUV_F_POOL_CAPSULES: *fd = {h->B.p_caps, c.max_capsules * 7, 0}; *width = c.max_capsules * 7; return 0;
+        case DOCKAUV_F_POOL_SPHERES: *fd = {h->B.p_sph, c.max_spheres * 4, 0}; *width = c.max_spheres * 4; return 0;
+    }
+    return fail(h, DOCKAUV_E_INVALID, "unknown field id %d", field);
+}
+
+bool is_current_field(int field) { return field == DOCKAUV_F_CURRENT || field == DOCKAUV_F_POOL_CURRENT; }
+
+size_t elem_size(dockauv_handle h, int kind) { return kind == 0 ? h->tsz : (kind == 1 ? 4 : 1); }
+
+void store_elem(dockauv_handle h, int kind, void* dst, size_t idx, double v) {
+    if (kind == 0) {
+        if (h->f64) static_cast<double*>(dst)[idx] = v; else static_cast<float*>(dst)[idx] = (float)v;
+    } else if (kind == 1) {
+        static_cast<int32_t*>(dst)[idx] = (int32_t)llround(v);
+    } else {
+        static_cast<uint8_t*>(dst)[idx] = (uint8_t)llround(v);
+    }
+}
+
+double load_elem(dockauv_handle h, int kind, const void* src, size_t idx) {
+    if (kind == 0) return h->f64 ? static_cast<const double*>(src)[idx] : (double)static_cast<const float*>(src)[idx];
+    if (kind == 1) return (double)static_cast<const int32_t*>(src)[idx];
+    return (double)static_cast<const uint8_t*>(src)[idx];
+}
+
+void set_io(StepIO& d, const dockauv_step_io& s) {
+    d.actions = s.actions;
+    d.noise = s.noise;
+    d.obs = s.obs;
+    d.reward = s.reward;
+    d.done = s.done;
+    d.reward_terms = s.reward_terms;
+    d.conditions = s.conditions;
+    d.nav = s.nav;
+    d.ray_dist = s.ray_dist;
+    d.terminal_obs = s.terminal_obs;
+}
+
+int launch(dockauv_handle h, const dockauv_step_io* io, hipStream_t stream) {
+    int rc;
+    if (h->f64) {
+        set_io(h->a64.io, *io);
+        rc = launch_step_f64(h->a64, h->vk, h->has_rays, 64, h->threads, stream);
+    } else {
+        set_io(h->a32.io, *io);
+        rc = launch_step_f32(h->a32, h->vk, h->has_rays, 64, h->threads, stream);
+    }
+    if (rc != 0) return fail(h, DOCKAUV_E_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    h->last_stream = stream;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dockauv_abi_version(void) { return DOCKAUV_ABI_VERSION; }
+
+const char* dockauv_build_info(void) {
+    return "libdockauv gfx950 (HIP), abi " "1" ", built " __DATE__ " " __TIME__;
+}
+
+const char* dockauv_last_error(dockauv_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
+    if (!cfg || !out) return fail(nullptr, DOCKAUV_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(dockauv_config) || cfg->abi_version != DOCKAUV_ABI_VERSION)
+        return fail(nullptr, DOCKAUV_E_INVALID, "dockauv_config size/ABI mismatch: got %u/%u, library has %zu/%d",
+                    cfg->struct_size, cfg->abi_version, sizeof(dockauv_config), DOCKAUV_ABI_VERSION);
+    const dockauv_config& c = *cfg;
+    if (c.n_envs <= 0) return fail(nullptr, DOCKAUV_E_INVALID, "n_envs must be > 0");
+    if (c.precision != DOCKAUV_F32 && c.precision != DOCKAUV_F64) return fail(nullptr, DOCKAUV_E_INVALID, "bad precision");
+    if (c.n_vehicles < 1 || c.n_vehicles > 2) return fail(nullptr, DOCKAUV_E_INVALID, "n_vehicles must be 1 or 2");
+    if (c.max_capsules < 0 || c.max_capsules > DOCKAUV_MAX_CAPSULES) return fail(nullptr, DOCKAUV_E_INVALID, "max_capsules out of range");
+    if (c.max_spheres < 0 || c.max_spheres > DOCKAUV_MAX_SPHERES) return fail(nullptr, DOCKAUV_E_INVALID, "max_spheres out of range");
+    if (c.n_v <= 0 || c.n_h <= 0 || (long)c.n_v * c.n_h > DOCKAUV_MAX_RAYS) return fail(nullptr, DOCKAUV_E_INVALID, "bad ray fan %d x %d", c.n_v, c.n_h);
+    if (c.blocksize_reduce <= 0) return fail(nullptr, DOCKAUV_E_INVALID, "blocksize_reduce must be > 0");
+    if (c.reward_set != 1 && c.reward_set != 2) return fail(nullptr, DOCKAUV_E_INVALID, "reward_set must be 1 or 2");
+    if (c.reset_mode < DOCKAUV_RESET_NONE || c.reset_mode > DOCKAUV_RESET_POOL)
+        return fail(nullptr, DOCKAUV_E_INVALID, "reset_mode %d not supported by this build", c.reset_mode);
+    if (!(c.t_step_size > 0)) return fail(nullptr, DOCKAUV_E_INVALID, "t_step_size must be > 0");
+    if (!c.ray_table) return fail(nullptr, DOCKAUV_E_INVALID, "ray_table is NULL");
+    for (int v = 0; v < c.n_vehicles; ++v) {
+        const dockauv_vehicle& vv = c.vehicle[v];
+        if (vv.n_u < 1 || vv.n_u > DOCKAUV_MAX_U) return fail(nullptr, DOCKAUV_E_INVALID, "vehicle %d: n_u out of range", v);
+        if (vv.kind != DOCKAUV_VEH_CONSTB && vv.kind != DOCKAUV_VEH_LAUV) return fail(nullptr, DOCKAUV_E_INVALID, "vehicle %d: bad kind", v);
+        if (vv.kind == DOCKAUV_VEH_LAUV && vv.n_u != 3) return fail(nullptr, DOCKAUV_E_INVALID, "LAUV needs n_u = 3");
+    }
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, DOCKAUV_E_NODEVICE, "no HIP device available (%s): libdockauv has no CPU fallback",
+                    e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, DOCKAUV_E_INVALID, "device %d out of range (have %d)", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, DOCKAUV_E_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+
+    dockauv_handle h = new dockauv_env_s();
+    h->cfg = c;
+    h->cfg.ray_table = nullptr;
+    h->device = device;
+    h->f64 = c.precision == DOCKAUV_F64;
+    h->tsz = h->f64 ? 8 : 4;
+    h->S = ((long)c.n_envs + 63) / 64 * 64;
+    h->n_rays = c.n_v * c.n_h;
+    const int blk = c.blocksize_reduce;
+    h->n_red = ((c.n_v + blk - 1) / blk) * ((c.n_h + blk - 1) / blk);
+    h->n_obs = DOCKAUV_N_OBS_BASE + h->n_red;
+    h->n_u_max = c.vehicle[0].n_u;
+    if (c.n_vehicles == 2 && c.vehicle[1].n_u > h->n_u_max) h->n_u_max = c.vehicle[1].n_u;
+    h->has_rays = (c.max_capsules + c.max_spheres) > 0;
+    h->threads = c.threads_per_group > 0 ? c.threads_per_group : 256;
+    if (c.n_vehicles == 2) {
+        if (!(c.vehicle[0].kind == DOCKAUV_VEH_CONSTB && b_is_diagonal(c.vehicle[0]) && c.vehicle[1].kind == DOCKAUV_VEH_LAUV)) {
+            delete h;
+            return fail(nullptr, DOCKAUV_E_INVALID, "mixed batches support vehicle[0] = diagonal-B (BlueROV2 joystick), vehicle[1] = LAUV");
+        }
+        h->vk = VK_MIXED;
+    } else if (c.vehicle[0].kind == DOCKAUV_VEH_LAUV) {
+        h->vk = VK_LAUV;
+    } else {
+        h->vk = b_is_diagonal(c.vehicle[0]) ? VK_JOY : VK_DENSEB;
+    }
+
+    const size_t S = (size_t)h->S, t = h->tsz;
+    int rc = 0;
+    Buffers& B = h->B;
+    B.stride = h->S;
+#define ALLOC(ptr, bytes)                                  \
+    if ((rc = dalloc(h, (void**)&(ptr), (bytes))) != 0) {  \
+        g_create_error = h->err;                           \
+        dockauv_destroy(h);                                \
+        return rc;                                         \
+    }
+    ALLOC(B.state, 12 * S * t);
+    ALLOC(B.u, kMaxU * S * t);
+    ALLOC(B.goal, 4 * S * t);
+    ALLOC(B.cur, 8 * S * t);
+    ALLOC(B.cum_reward, S * t);
+    ALLOC(B.t_steps, S * 4);
+    ALLOC(B.episode, S * 4);
+    ALLOC(B.veh_id, S);
+    ALLOC(B.caps, (size_t)c.max_capsules * 7 * S * t);
+    ALLOC(B.sph, (size_t)c.max_spheres * 4 * S * t);
+    ALLOC(B.p_pose, 6 * S * t);
+    ALLOC(B.p_goal, 4 * S * t);
+    ALLOC(B.p_cur, 8 * S * t);
+    ALLOC(B.p_caps, (size_t)c.max_capsules * 7 * S * t);
+    ALLOC(B.p_sph, (size_t)c.max_spheres * 4 * S * t);
+    void* rays_dev = nullptr;
+    ALLOC(rays_dev, (size_t)h->n_rays * 4 * t);
+    {
+        std::vector<unsigned char> tmp((size_t)h->n_rays * 4 * t);
+        for (int i = 0; i < h->n_rays * 4; ++i) store_elem(h, 0, tmp.data(), i, c.ray_table[i]);
+        e = hipMemcpy(rays_dev, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            fail(nullptr, DOCKAUV_E_HIP, "ray table upload: %s", hipGetErrorString(e));
+            dockauv_destroy(h);
+            return DOCKAUV_E_HIP;
+        }
+    }
+    B.rays = rays_dev;
+    // host-pointer staging buffers
+    const size_t N = (size_t)c.n_envs;
+    ALLOC(h->d_actions, N * h->n_u_max * t);
+    ALLOC(h->d_noise, N * t);
+    ALLOC(h->d_obs, N * h->n_obs * 4);
+    ALLOC(h->d_reward, N * t);
+    ALLOC(h->d_done, N);
+    ALLOC(h->d_terms, N * kNRew * t);
+    ALLOC(h->d_cond, N);
+    ALLOC(h->d_nav, N * 4 * t);
+    ALLOC(h->d_raydist, N * h->n_rays * t);
+    ALLOC(h->d_termobs, N * h->n_obs * 4);
+#undef ALLOC
+
+    if (h->f64) {
+        fill_env(h->a64.E, *h);
+        for (int v = 0; v < c.n_vehicles; ++v) fill_vehicle(h->a64.V[v], c.vehicle[v]);
+        h->a64.B = B;
+    } else {
+        fill_env(h->a32.E, *h);
+        for (int v = 0; v < c.n_vehicles; ++v) fill_vehicle(h->a32.V[v], c.vehicle[v]);
+        h->a32.B = B;
+    }
+    // the dynamic-LDS request must fit the 160 KiB of a gfx950 CU (64 KiB without opting in)
+    size_t lds = h->f64 ? lds_bytes<double>(64, c.max_capsules, c.max_spheres, h->n_rays, h->n_obs, h->has_rays)
+                        : lds_bytes<float>(64, c.max_capsules, c.max_spheres, h->n_rays, h->n_obs, h->has_rays);
+    if (lds > 64 * 1024) {
+        fail(nullptr, DOCKAUV_E_INVALID, "configuration needs %zu B of LDS per group (> 64 KiB): fewer rays/obstacles", lds);
+        dockauv_destroy(h);
+        return DOCKAUV_E_INVALID;
+    }
+    *out = h;
+    return 0;
+}
+
+int dockauv_destroy(dockauv_handle h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+    return 0;
+}
+
+int dockauv_n_obs(dockauv_handle h) { return h ? h->n_obs : DOCKAUV_E_INVALID; }
+int dockauv_n_rays(dockauv_handle h) { return h ? h->n_rays : DOCKAUV_E_INVALID; }
+int dockauv_n_u(dockauv_handle h) { return h ? h->n_u_max : DOCKAUV_E_INVALID; }
+
+int dockauv_field_width(dockauv_handle h, int field) {
+    if (!h) return DOCKAUV_E_INVALID;
+    FieldDesc fd;
+    int w = 0;
+    int rc = field_info(h, field, &fd, &w);
+    return rc ? rc : w;
+}
+
+int dockauv_set_field(dockauv_handle h, int field, int first, int count, const double* src) {
+    if (!h || !src) return fail(h, DOCKAUV_E_INVALID, "null argument");
+    FieldDesc fd;
+    int width = 0;
+    int rc = field_info(h, field, &fd, &width);
+    if (rc) return rc;
+    if (first < 0 || count < 0 || (long)first + count > h->cfg.n_envs) return fail(h, DOCKAUV_E_RANGE, "env range [%d, %d) outside [0, %d)", first, first + count, h->cfg.n_envs);
+    if (count == 0 || fd.rows == 0) return 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t es = elem_size(h, fd.kind);
+    std::vector<unsigned char> tmp((size_t)fd.rows * count * es);
+    if (is_current_field(field)) {
+        // host (V_c, V_min, V_max, alpha, beta) -> device rows (V_c, dir xyz, V_min, V_max, alpha, beta);
+        // dir = (cos a cos b, sin b, sin a cos b): objects/current.py:70-74
+        for (int i = 0; i < count; ++i) {
+            const double* s = src + (size_t)i * 5;
+            const double a = s[3], b = s[4];
+            const double row[8] = {s[0], std::cos(a) * std::cos(b), std::sin(b), std::sin(a) * std::cos(b), s[1], s[2], a, b};
+            for (int k = 0; k < 8; ++k) store_elem(h, 0, tmp.data(), (size_t)k * count + i, row[k]);
+        }
+    } else {
+        for (int i = 0; i < count; ++i)
+            for (int k = 0; k < width; ++k) store_elem(h, fd.kind, tmp.data(), (size_t)k * count + i, src[(size_t)i * width + k]);
+    }
+    unsigned char* dst = static_cast<unsigned char*>(fd.base) + (size_t)first * es;
+    HIP_TRY(h, hipMemcpy2D(dst, (size_t)h->S * es, tmp.data(), (size_t)count * es, (size_t)count * es, fd.rows, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int dockauv_get_field(dockauv_handle h, int field, int first, int count, double* dst) {
+    if (!h || !dst) return fail(h, DOCKAUV_E_INVALID, "null argument");
+    FieldDesc fd;
+    int width = 0;
+    int rc = field_info(h, field, &fd, &width);
+    if (rc) return rc;
+    if (first < 0 || count < 0 || (long)first + count > h->cfg.n_envs) return fail(h, DOCKAUV_E_RANGE, "env range [%d, %d) outside [0, %d)", first, first + count, h->cfg.n_envs);
+    if (count == 0 || fd.rows == 0) return 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream)); else HIP_TRY(h, hipDeviceSynchronize());
+    const size_t es = elem_size(h, fd.kind);
+    std::vector<unsigned char> tmp((size_t)fd.rows * count * es);
+    const unsigned char* srcp = static_cast<const unsigned char*>(fd.base) + (size_t)first * es;
+    HIP_TRY(h, hipMemcpy2D(tmp.data(), (size_t)count * es, srcp, (size_t)h->S * es, (size_t)count * es, fd.rows, hipMemcpyDeviceToHost));
+    if (is_current_field(field)) {
+        static const int rows[5] = {0, 4, 5, 6, 7};
+        for (int i = 0; i < count; ++i)
+            for (int k = 0; k < 5; ++k) dst[(size_t)i * 5 + k] = load_elem(h, 0, tmp.data(), (size_t)rows[k] * count + i);
+    } else {
+        for (int i = 0; i < count; ++i)
+            for (int k = 0; k < width; ++k) dst[(size_t)i * width + k] = load_elem(h, fd.kind, tmp.data(), (size_t)k * count + i);
+    }
+    return 0;
+}
+
+int dockauv_reset_envs(dockauv_handle h, int first, int count) {
+    if (!h) return DOCKAUV_E_INVALID;
+    if (first < 0 || count < 0 || (long)first + count > h->cfg.n_envs) return fail(h, DOCKAUV_E_RANGE, "env range outside [0, %d)", h->cfg.n_envs);
+    if (count == 0) return 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream)); else HIP_TRY(h, hipDeviceSynchronize());
+    const size_t t = h->tsz, S = (size_t)h->S;
+    HIP_TRY(h, hipMemset2D(static_cast<unsigned char*>(h->B.state) + first * t, S * t, 0, count * t, 12));
+    HIP_TRY(h, hipMemset2D(static_cast<unsigned char*>(h->B.u) + first * t, S * t, 0, count * t, kMaxU));
+    HIP_TRY(h, hipMemset(static_cast<unsigned char*>(h->B.cum_reward) + first * t, 0, count * t));
+    HIP_TRY(h, hipMemset(h->B.t_steps + first, 0, count * 4));
+    std::vector<int32_t> ep(count);
+    HIP_TRY(h, hipMemcpy(ep.data(), h->B.episode + first, count * 4, hipMemcpyDeviceToHost));
+    for (auto& x : ep) x += 1;
+    HIP_TRY(h, hipMemcpy(h->B.episode + first, ep.data(), count * 4, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int dockauv_step(dockauv_handle h, const dockauv_step_io* io, void* hip_stream) {
+    if (!h || !io) return fail(h, DOCKAUV_E_INVALID, "null argument");
+    if (!io->actions || !io->obs || !io->reward || !io->done) return fail(h, DOCKAUV_E_INVALID, "actions/obs/reward/done must not be NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch(h, io, (hipStream_t)hip_stream);
+}
+
+int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io) {
+    if (!h || !io) return fail(h, DOCKAUV_E_INVALID, "null argument");
+    if (!io->actions || !io->obs || !io->reward || !io->done) return fail(h, DOCKAUV_E_INVALID, "actions/obs/reward/done must not be NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t N = (size_t)h->cfg.n_envs, t = h->tsz;
+    HIP_TRY(h, hipMemcpy(h->d_actions, io->actions, N * h->n_u_max * t, hipMemcpyHostToDevice));
+    if (io->noise) HIP_TRY(h, hipMemcpy(h->d_noise, io->noise, N * t, hipMemcpyHostToDevice));
+    dockauv_step_io d{};
+    d.actions = h->d_actions;
+    d.noise = io->noise ? h->d_noise : nullptr;
+    d.obs = h->d_obs;
+    d.reward = h->d_reward;
+    d.done = h->d_done;
+    d.reward_terms = io->reward_terms ? h->d_terms : nullptr;
+    d.conditions = io->conditions ? h->d_cond : nullptr;
+    d.nav = io->nav ? h->d_nav : nullptr;
+    d.ray_dist = io->ray_dist ? h->d_raydist : nullptr;
+    d.terminal_obs = io->terminal_obs ? h->d_termobs : nullptr;
+    int rc = launch(h, &d, nullptr);
+    if (rc) return rc;
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(io->obs, h->d_obs, N * h->n_obs * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(io->reward, h->d_reward, N * t, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(io->done, h->d_done, N, hipMemcpyDeviceToHost));
+    if (io->reward_terms) HIP_TRY(h, hipMemcpy(io->reward_terms, h->d_terms, N * kNRew * t, hipMemcpyDeviceToHost));
+    if (io->conditions) HIP_TRY(h, hipMemcpy(io->conditions, h->d_cond, N, hipMemcpyDeviceToHost));
+    if (io->nav) HIP_TRY(h, hipMemcpy(io->nav, h->d_nav, N * 4 * t, hipMemcpyDeviceToHost));
+    if (io->ray_dist) HIP_TRY(h, hipMemcpy(io->ray_dist, h->d_raydist, N * h->n_rays * t, hipMemcpyDeviceToHost));
+    if (io->terminal_obs) HIP_TRY(h, hipMemcpy(io->terminal_obs, h->d_termobs, N * h->n_obs * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dockauv_synchronize(dockauv_handle h) {
+    if (!h) return DOCKAUV_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream)); else HIP_TRY(h, hipDeviceSynchronize());
+    return 0;
+}
+
+int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_stream, int steps, double* avg_us) {
+    if (!h || !io || !avg_us || steps <= 0) return fail(h, DOCKAUV_E_INVALID, "bad argument");
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    HIP_TRY(h, hipEventRecord(e0, s));
+    for (int i = 0; i < steps; ++i) {
+        int rc = launch(h, io, s);
+        if (rc) return rc;
+    }
+    HIP_TRY(h, hipEventRecord(e1, s));
+    HIP_TRY(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = (double)ms * 1000.0 / steps;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// dockauv_device.h -- parameter blocks passed BY VALUE to the step kernel (kernarg segment => scalar loads,
+// wave-uniform SGPR operands) and the struct-of-arrays buffer table.  Internal to libdockauv.so.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dockauv {
+
+constexpr int kMaxU = 8;
+constexpr int kNRew = 13;
+
+// indices into VehicleP::lauv (same order as dockauv_vehicle::lauv in include/dockauv.h)
+enum LauvIdx {
+    L_Y_r = 0, L_Y_rr, L_Y_urf, L_Z_q, L_Z_qq, L_Z_uqf, L_M_w, L_M_ww, L_M_uw, L_N_v, L_N_vv, L_N_uv,
+    L_Y_uv, L_Z_uw, L_M_uqf, L_N_urf, L_Y_uudr, L_Z_uuds, L_M_uuds, L_N_uudr, L_COUNT
+};
+
+// kernel-side vehicle kinds (template parameter VK)
+enum VehKind { VK_JOY = 0, VK_DENSEB = 1, VK_LAUV = 2, VK_MIXED = 3 };
+
+template <typename T>
+struct VehicleP {
+    T m;
+    T gWB, gx, gy, gz;   // W-B, x_G W - x_B B, y_G W - y_B B, z_G W - z_B B   (statespace.py:353-397)
+    T rg[3];
+    T Ib[9];
+    T ma[6];
+    T dl[6], dq[6];
+    T Minv[36];
+    T B[6 * kMaxU];      // VK_DENSEB: dense row-major; VK_JOY: only the diagonal B[i*kMaxU+i] is read
+    T ulo[kMaxU], uhalf[kMaxU];  // u = ulo + (uhi-ulo) * (clip(a)+1)/2 ; uhalf = (uhi-ulo)
+    T lauv[L_COUNT];
+    int n_u;
+};
+
+template <typename T>
+struct EnvP {
+    int n_envs, max_timesteps, reward_set, reset_mode, scenario;
+    int n_v, n_h, blk, n_vr, n_hr, n_rays, n_red, n_obs;
+    int max_cap, max_sph, n_u_max;
+    unsigned long long seed;
+    T h, lp_alpha, mu;
+    T dmax, dtol, max_att, safety;
+    T vel_max[6];
+    T w_d, w_dth, w_dpsi, w_phi, w_th, w_thdot, w_oa;
+    T w_done[5];
+    T w_act[kMaxU];      // action_reward_factors[i]
+    T ray_max, alpha_max, beta_max;
+};
+
+// All per-env arrays are struct-of-arrays: element (field k, env i) lives at base[k * stride + i], stride = n_envs
+// rounded up to a multiple of 64 so that every row starts 256-B aligned.
+struct Buffers {
+    void* state;      // T [12][S]
+    void* u;          // T [kMaxU][S]
+    void* goal;       // T [4][S]   x y z heading
+    void* cur;        // T [6][S]   V_c, dir_x, dir_y, dir_z (NED unit vector), V_min, V_max
+    void* cum_reward; // T [S]
+    int32_t* t_steps; // [S]
+    int32_t* episode; // [S]
+    uint8_t* veh_id;  // [S]
+    void* caps;       // T [max_cap][7][S]
+    void* sph;        // T [max_sph][4][S]
+    // next-episode pool (DOCKAUV_RESET_POOL)
+    void* p_pose;     // T [6][S]
+    void* p_goal;     // T [4][S]
+    void* p_cur;      // T [6][S]
+    void* p_caps;     // T [max_cap][7][S]
+    void* p_sph;      // T [max_sph][4][S]
+    // ray table: T [n_rays][4] = body-frame unit direction xyz, obstacle-avoidance weight beta_oa
+    const void* rays;
+    long stride;
+};
+
+struct StepIO {
+    const void* actions;
+    const void* noise;
+    float* obs;
+    void* reward;
+    uint8_t* done;
+    void* reward_terms;
+    uint8_t* conditions;
+    void* nav;
+    void* ray_dist;
+    float* terminal_obs;
+};
+
+template <typename T, int NV>
+struct KernelArgs {
+    EnvP<T> E;
+    VehicleP<T> V[NV];
+    Buffers B;
+    StepIO io;
+};
+
+// LDS hand-over layout between the env phase and the ray stage
+constexpr int kCapFields = 14;   // ba(3) oa(3) oc2(3) baba baoa cc c2b c2t   (objects/shape.py:341-363)
+constexpr int kSphFields = 4;    // oc(3) |oc|^2 - r^2
+constexpr int kPoseFields = 14;  // pos(3) R(9) n_cap n_sph
+
+template <typename T>
+inline size_t lds_bytes(int epg, int max_cap, int max_sph, int n_rays, int n_obs, bool rays) {
+    size_t t_elems = rays ? (size_t)epg * (kPoseFields + kCapFields * max_cap + kSphFields * max_sph + n_rays) : 0;
+    size_t bytes = t_elems * sizeof(T);
+    bytes = (bytes + 15) & ~(size_t)15;
+    return bytes + (size_t)epg * n_obs * sizeof(float);
+}
+
+// launch one step; implemented in dockauv_kernels.hip.  vk = VehKind, has_rays = obstacles present.
+// returns a hipError_t as int.
+int launch_step_f32(const KernelArgs<float, 2>& a, int vk, bool has_rays, int envs_per_group, int threads, void* stream);
+int launch_step_f64(const KernelArgs<double, 2>& a, int vk, bool has_rays, int envs_per_group, int threads, void* stream);
+
+}  // namespace dockauv

@@ -1,0 +1,492 @@
+"""
+BatchedDocking3d -- N independent docking3d environments stepped by one HIP kernel launch per step.
+
+Host-side mirror of the reference's ``BaseDocking3d`` (envs/docking3d.py:31-704) for a batch: same config schema,
+same observation / reward / done semantics, same reset draw order; SB3 ``VecEnv`` call surface (``num_envs``,
+``reset``, ``step_async`` / ``step_wait`` / ``step``, auto-reset with ``infos[i]["terminal_observation"]``).
+All arithmetic of ``step`` happens in libdockauv.so (gym_dockauv_amd/csrc); this class only builds the C config,
+stages episodes (scenario generation stays on the host, like the reference's ``reset``) and moves pointers.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+
+from .. import _capi, scenarios
+from ..config.env_config import BASE_CONFIG
+from ..objects.radar import RadarLayout
+from ..objects.vehicle_models import VehicleModel, make_vehicle
+
+META_DATA_REWARD = ["Nav_delta_d", "Nav_delta_theta", "Nav_delta_psi", "Att_phi", "Att_theta", "Thetadot",
+                    "obstacle_avoid", "action", "Done-Goal_reached", "Done-out_pos", "Done-out_att", "Done-max_t",
+                    "Done-collision"]                      # envs/docking3d.py:160-178
+META_DATA_DONE = META_DATA_REWARD[8:]
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is optional); same attributes the reference sets
+    (envs/docking3d.py:116-125)."""
+
+    def __init__(self, low, high, dtype=np.float32):
+        self.low = np.asarray(low, dtype=dtype)
+        self.high = np.asarray(high, dtype=dtype)
+        self.dtype = np.dtype(dtype)
+        self.shape = self.low.shape
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+    def __repr__(self):
+        return f"Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype.name})"
+
+
+def make_box(low, high, dtype=np.float32):
+    try:
+        import gym  # type: ignore
+        return gym.spaces.Box(low=np.asarray(low, dtype=dtype), high=np.asarray(high, dtype=dtype), dtype=dtype)
+    except Exception:
+        return Box(low, high, dtype)
+
+
+class BatchedDocking3d:
+    """
+    :param env_config: dict with the reference's key schema (config/env_config.py)
+    :param num_envs: envs on this device
+    :param scenario: one of scenarios.SCENARIOS (the reference's env class names + "SphereDocking3d")
+    :param device: HIP device ordinal
+    :param precision: "f32" (product path) or "f64" (validation instantiation of the same kernels)
+    :param auto_reset: VecEnv semantics (in-kernel reset from the host-staged pool); False = gym.Env semantics
+    :param rng: "per_env" -> one legacy ``RandomState`` per env, reference draw order incl. the per-step normal burn
+                (parity with ``reset(seed)`` of the reference); "batched" -> one vectorised generator (throughput)
+    :param vehicles: optional per-env vehicle names for a mixed batch, e.g. ["BlueROV2", "LAUV", ...]
+    """
+
+    def __init__(self, env_config: dict = BASE_CONFIG, num_envs: int = 1, scenario: str = "SimpleDocking3d",
+                 device: int = 0, precision: str = "f32", auto_reset: bool = True, rng: str = "per_env",
+                 vehicles: Optional[Sequence[str]] = None, max_capsules: Optional[int] = None,
+                 max_spheres: Optional[int] = None, threads_per_group: int = 0,
+                 vehicle_models: Optional[Sequence[VehicleModel]] = None, current_mu: float = scenarios.CURRENT_MU):
+        if scenario not in scenarios.SCENARIOS:
+            raise KeyError(f"Not valid scenario, available options are {scenarios.SCENARIOS}")
+        self.config = copy.deepcopy(env_config)
+        self.scenario = scenario
+        self.num_envs = int(num_envs)
+        self.device = int(device)
+        self.precision = precision
+        self.auto_reset = bool(auto_reset)
+        self.rng_mode = rng
+        self.current_mu = float(current_mu)
+        self._lib = _capi.load_library()
+        self._np_t = np.float64 if precision == "f64" else np.float32
+
+        # vehicles
+        if vehicle_models is not None:
+            self.vehicle_models = list(vehicle_models)
+        elif vehicles is not None:
+            names = list(dict.fromkeys(vehicles))
+            if names not in (["BlueROV2", "LAUV"], ["LAUV", "BlueROV2"], ["BlueROV2"], ["LAUV"]):
+                raise ValueError("mixed batches support BlueROV2 + LAUV")
+            self.vehicle_models = [make_vehicle(n) for n in (["BlueROV2", "LAUV"] if len(names) == 2 else names)]
+        else:
+            self.vehicle_models = [make_vehicle(self.config["vehicle"])]
+        self.auv = self.vehicle_models[0]          # `env.auv.u_bound` is what train.py touches (train.py:102,191)
+        self.n_u = max(int(m.u_bound.shape[0]) for m in self.vehicle_models)
+        if vehicles is not None and len(self.vehicle_models) == 2:
+            self.vehicle_id = np.array([0 if v == "BlueROV2" else 1 for v in vehicles], dtype=np.float64)
+            if self.vehicle_id.shape[0] != self.num_envs:
+                raise ValueError("len(vehicles) must equal num_envs")
+        else:
+            self.vehicle_id = np.zeros(self.num_envs)
+
+        # ray fan (envs/docking3d.py:104-105)
+        self.radar_args = self.config["radar"]
+        self.radar = RadarLayout(**self.radar_args)
+        self.n_obs_without_radar = 16
+        self.n_observations = self.n_obs_without_radar + self.radar.n_rays_reduced
+        self.n_rewards = 13
+        self.n_cont_rewards = 8
+        self.meta_data_reward = META_DATA_REWARD
+        self.meta_data_done = META_DATA_DONE
+
+        self.max_capsules = scenarios.N_CAPSULES[scenario] if max_capsules is None else int(max_capsules)
+        self.max_spheres = scenarios.N_SPHERES[scenario] if max_spheres is None else int(max_spheres)
+
+        # spaces (envs/docking3d.py:116-125)
+        ub = np.zeros((self.n_u, 2))
+        ub[: self.auv.u_bound.shape[0]] = self.auv.u_bound
+        self.action_space = make_box(ub[:, 0], ub[:, 1], np.float32)
+        obs_low = -np.ones(self.n_observations)
+        obs_low[0] = 0
+        obs_low[self.n_obs_without_radar:] = 0
+        self.observation_space = make_box(obs_low, np.ones(self.n_observations), np.float32)
+
+        self._handle = C.c_void_p()
+        self._ray_table = self.radar.ray_table()
+        cfg = self._build_config()
+        rc = self._lib.dockauv_create(C.byref(cfg), self.device, C.byref(self._handle))
+        _capi.check(self._lib, None, rc, "dockauv_create")
+        assert self._lib.dockauv_n_obs(self._handle) == self.n_observations
+        if len(self.vehicle_models) == 2:
+            self.set_field(_capi.F_VEHICLE_ID, self.vehicle_id[:, None])
+
+        # host-side episode bookkeeping
+        N = self.num_envs
+        self._seeds: Optional[np.ndarray] = None
+        self._rs: List[Optional[np.random.RandomState]] = [None] * N
+        self._gen = np.random.default_rng()
+        self._steps_since_reset = np.zeros(N, dtype=np.int64)     # per-step normal draws to burn (current.py:88)
+        self.episode = np.zeros(N, dtype=np.int64)
+        self.t_total_steps = 0
+        self._actions = None
+        self._static_spheres: Optional[np.ndarray] = None
+        # host output buffers (host-pointer path)
+        self._obs = np.zeros((N, self.n_observations), dtype=np.float32)
+        self._rew = np.zeros(N, dtype=self._np_t)
+        self._done = np.zeros(N, dtype=np.uint8)
+        self._terms = np.zeros((N, 13), dtype=self._np_t)
+        self._cond = np.zeros(N, dtype=np.uint8)
+        self._nav = np.zeros((N, 4), dtype=self._np_t)
+        self._ray = np.zeros((N, self.radar.n_rays), dtype=self._np_t)
+        self._termobs = np.zeros((N, self.n_observations), dtype=np.float32)
+
+    # ------------------------------------------------------------------------------------------ config
+    def _build_config(self) -> _capi.Config:
+        c = self.config
+        cfg = _capi.Config()
+        cfg.struct_size = C.sizeof(_capi.Config)
+        cfg.abi_version = _capi.ABI_VERSION
+        cfg.n_envs = self.num_envs
+        cfg.precision = _capi.F64 if self.precision == "f64" else _capi.F32
+        cfg.n_vehicles = len(self.vehicle_models)
+        cfg.reset_mode = _capi.RESET_POOL if self.auto_reset else _capi.RESET_NONE
+        cfg.scenario = _capi.SCN[self.scenario]
+        cfg.max_timesteps = int(c["max_timesteps"])
+        cfg.reward_set = int(c["reward_set"])
+        cfg.max_capsules = self.max_capsules
+        cfg.max_spheres = self.max_spheres
+        cfg.n_v, cfg.n_h = self.radar.n_vertical, self.radar.n_horizontal
+        cfg.blocksize_reduce = self.radar.blocksize_reduce
+        cfg.envs_per_group = 0
+        cfg.threads_per_group = 0
+        cfg.seed = 0
+        cfg.t_step_size = float(c["t_step_size"])
+        cfg.lowpass_T1 = 0.2
+        cfg.current_mu = self.current_mu
+        cfg.max_dist_from_goal = float(c["max_dist_from_goal"])
+        cfg.max_attitude = float(c["max_attitude"])
+        cfg.dist_goal_reached_tol = float(c["dist_goal_reached_tol"])
+        cfg.vel_max[:] = [float(c[k]) for k in ("u_max", "v_max", "w_max", "p_max", "q_max", "r_max")]
+        cfg.safety_radius = float(self.auv.safety_radius)
+        rf = c["reward_factors"]
+        cfg.w_d, cfg.w_delta_theta, cfg.w_delta_psi = rf["w_d"], rf["w_delta_theta"], rf["w_delta_psi"]
+        cfg.w_phi, cfg.w_theta, cfg.w_Thetadot, cfg.w_oa = rf["w_phi"], rf["w_theta"], rf["w_Thetadot"], rf["w_oa"]
+        cfg.w_done[:] = [rf["w_goal"], rf["w_deltad_max"], rf["w_Theta_max"], rf["w_t_max"], rf["w_col"]]
+        arf = np.broadcast_to(np.asarray(c["action_reward_factors"], dtype=float), (self.n_u,))
+        w = np.zeros(_capi.MAX_U)
+        w[: self.n_u] = arf
+        cfg.action_reward_factors[:] = w.tolist()
+        cfg.radar_max_dist = self.radar.max_dist
+        cfg.radar_alpha_max, cfg.radar_beta_max = self.radar.alpha_max, self.radar.beta_max
+        cfg.ray_table = self._ray_table.ctypes.data_as(C.POINTER(C.c_double))
+        for i, m in enumerate(self.vehicle_models):
+            cfg.vehicle[i] = m.to_capi()
+        return cfg
+
+    # ------------------------------------------------------------------------------------------ field I/O
+    def set_field(self, field: int, values: np.ndarray, first: int = 0) -> None:
+        a = np.ascontiguousarray(values, dtype=np.float64)
+        if a.ndim == 1:
+            a = a[:, None]
+        width = self._lib.dockauv_field_width(self._handle, field)
+        if width == 0 and a.size == 0:
+            return
+        if a.shape[1] != width:
+            raise ValueError(f"field {field}: expected width {width}, got {a.shape[1]}")
+        rc = self._lib.dockauv_set_field(self._handle, field, first, a.shape[0], a.ctypes.data_as(C.c_void_p))
+        _capi.check(self._lib, self._handle, rc, "dockauv_set_field")
+
+    def get_field(self, field: int, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        count = self.num_envs - first if count is None else count
+        width = self._lib.dockauv_field_width(self._handle, field)
+        out = np.zeros((count, max(width, 0)), dtype=np.float64)
+        if width > 0 and count > 0:
+            rc = self._lib.dockauv_get_field(self._handle, field, first, count, out.ctypes.data_as(C.c_void_p))
+            _capi.check(self._lib, self._handle, rc, "dockauv_get_field")
+        return out
+
+    def _set_rows(self, field: int, idx: np.ndarray, values: np.ndarray) -> None:
+        """set_field for an arbitrary (sorted) index set, as contiguous runs."""
+        idx = np.asarray(idx)
+        if idx.size == 0:
+            return
+        breaks = np.flatnonzero(np.diff(idx) != 1) + 1
+        for run_idx, run_val in zip(np.split(idx, breaks), np.split(values, breaks)):
+            self.set_field(field, run_val, first=int(run_idx[0]))
+
+    # convenience views used by callers of the reference (datastorage.py:298-300, train.py:191)
+    @property
+    def state(self) -> np.ndarray:
+        return self.get_field(_capi.F_STATE)
+
+    @property
+    def position(self) -> np.ndarray:
+        return self.state[:, 0:3]
+
+    @property
+    def attitude(self) -> np.ndarray:
+        return self.state[:, 3:6]
+
+    @property
+    def u(self) -> np.ndarray:
+        return self.get_field(_capi.F_U)[:, : self.n_u]
+
+    @property
+    def t_steps(self) -> np.ndarray:
+        return self.get_field(_capi.F_TSTEPS)[:, 0].astype(np.int64)
+
+    @property
+    def cumulative_reward(self) -> np.ndarray:
+        return self.get_field(_capi.F_CUM_REWARD)[:, 0]
+
+    @property
+    def goal_location(self) -> np.ndarray:
+        return self.get_field(_capi.F_GOAL)[:, 0:3]
+
+    # ------------------------------------------------------------------------------------------ episodes
+    def seed(self, seed: Optional[Union[int, Sequence[int]]] = None) -> List[Optional[int]]:
+        """VecEnv.seed: env i gets seed + i (SB3 convention) or seed[i]."""
+        N = self.num_envs
+        if seed is None:
+            self._seeds = None
+            return [None] * N
+        seeds = np.asarray(seed)
+        if seeds.ndim == 0:
+            seeds = int(seeds) + np.arange(N)
+        self._seeds = seeds.astype(np.int64)
+        return self._seeds.tolist()
+
+    def _uniforms(self, idx: np.ndarray, reseed: bool) -> np.ndarray:
+        k = scenarios.N_DRAWS[self.scenario]
+        if self.rng_mode == "batched":
+            return self._gen.random((idx.size, k))
+        U = np.empty((idx.size, k))
+        for j, i in enumerate(idx):
+            if reseed and self._seeds is not None:
+                self._rs[i] = np.random.RandomState(int(self._seeds[i]))      # docking3d.py:296-298
+            elif self._rs[i] is None:
+                self._rs[i] = np.random.RandomState()
+            elif self._steps_since_reset[i] > 0:
+                self._rs[i].normal(size=int(self._steps_since_reset[i]))       # Q11: one normal per elapsed step
+            U[j] = self._rs[i].random_sample(k)
+        self._steps_since_reset[idx] = 0
+        return U
+
+    def generate_episodes(self, idx: np.ndarray, reseed: bool = False) -> Dict[str, np.ndarray]:
+        ep = scenarios.episodes_from_uniforms(self.scenario, self._uniforms(idx, reseed), self.config["max_attitude"],
+                                              self.config["max_dist_from_goal"], self.max_capsules, self.max_spheres)
+        if self.scenario == "SphereDocking3d":
+            if self._static_spheres is None:
+                self._static_spheres = np.stack([
+                    scenarios.sphere_shell(np.random.RandomState(10_000 + i), np.zeros(3), self.max_spheres).reshape(-1)
+                    for i in range(self.num_envs)])
+            ep["spheres"] = self._static_spheres[idx]
+        return ep
+
+    def load_episodes(self, idx: np.ndarray, ep: Dict[str, np.ndarray], pool: bool = False) -> None:
+        """Write episodes into the live arrays (reset) or into the next-episode pool."""
+        idx = np.asarray(idx)
+        if pool:
+            self._set_rows(_capi.F_POOL_POSE, idx, ep["pose"])
+            self._set_rows(_capi.F_POOL_GOAL, idx, ep["goal"])
+            self._set_rows(_capi.F_POOL_CURRENT, idx, ep["current"])
+            if self.max_capsules:
+                self._set_rows(_capi.F_POOL_CAPSULES, idx, ep["capsules"])
+            if self.max_spheres:
+                self._set_rows(_capi.F_POOL_SPHERES, idx, ep["spheres"])
+            return
+        state = np.zeros((idx.size, 12))
+        state[:, 0:6] = ep["pose"]
+        self._set_rows(_capi.F_STATE, idx, state)
+        self._set_rows(_capi.F_GOAL, idx, ep["goal"])
+        self._set_rows(_capi.F_CURRENT, idx, ep["current"])
+        if self.max_capsules:
+            self._set_rows(_capi.F_CAPSULES, idx, ep["capsules"])
+        if self.max_spheres:
+            self._set_rows(_capi.F_SPHERES, idx, ep["spheres"])
+
+    def reset(self, seed: Optional[Union[int, Sequence[int]]] = None, return_info: bool = False, options=None):
+        """Reset every env (BaseDocking3d.reset, docking3d.py:222-322).  Returns the all-zero observation (Q8)."""
+        if seed is not None:
+            self.seed(seed)
+        idx = np.arange(self.num_envs)
+        rc = self._lib.dockauv_reset_envs(self._handle, 0, self.num_envs)
+        _capi.check(self._lib, self._handle, rc, "dockauv_reset_envs")
+        self.load_episodes(idx, self.generate_episodes(idx, reseed=seed is not None or self._seeds is not None))
+        self.episode += 1
+        if self.auto_reset:
+            self.load_episodes(idx, self.generate_episodes_for_pool(idx), pool=True)
+        obs = np.zeros((self.num_envs, self.n_observations), dtype=np.float32)
+        if return_info:
+            return obs, [{} for _ in range(self.num_envs)]
+        return obs
+
+    def generate_episodes_for_pool(self, idx: np.ndarray) -> Dict[str, np.ndarray]:
+        """Pool entries are drawn when they are CONSUMED in parity mode (the burn count is only known then); at
+        staging time we park a valid placeholder drawn from the batched generator."""
+        if self.rng_mode == "batched":
+            return self.generate_episodes(idx)
+        k = scenarios.N_DRAWS[self.scenario]
+        ep = scenarios.episodes_from_uniforms(self.scenario, self._gen.random((idx.size, k)), self.config["max_attitude"],
+                                              self.config["max_dist_from_goal"], self.max_capsules, self.max_spheres)
+        if self.scenario == "SphereDocking3d" and self._static_spheres is not None:
+            ep["spheres"] = self._static_spheres[idx]
+        return ep
+
+    def reset_envs(self, idx: Sequence[int], episodes: Optional[Dict[str, np.ndarray]] = None) -> None:
+        """gym.Env-style reset of selected envs (auto_reset=False callers)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        if idx.size == 0:
+            return
+        breaks = np.flatnonzero(np.diff(idx) != 1) + 1
+        for run in np.split(idx, breaks):
+            rc = self._lib.dockauv_reset_envs(self._handle, int(run[0]), int(run.size))
+            _capi.check(self._lib, self._handle, rc, "dockauv_reset_envs")
+        self.load_episodes(idx, episodes if episodes is not None else self.generate_episodes(idx))
+        self.episode[idx] += 1
+
+    # ------------------------------------------------------------------------------------------ step
+    def _io(self, actions: np.ndarray, noise: Optional[np.ndarray], extras: bool) -> _capi.StepIO:
+        io = _capi.StepIO()
+        io.actions = actions.ctypes.data
+        io.noise = noise.ctypes.data if noise is not None else None
+        io.obs = self._obs.ctypes.data
+        io.reward = self._rew.ctypes.data
+        io.done = self._done.ctypes.data
+        io.conditions = self._cond.ctypes.data
+        io.terminal_obs = self._termobs.ctypes.data if self.auto_reset else None
+        if extras:
+            io.reward_terms = self._terms.ctypes.data
+            io.nav = self._nav.ctypes.data
+            io.ray_dist = self._ray.ctypes.data
+        return io
+
+    def step_async(self, actions: np.ndarray) -> None:
+        self._actions = actions
+
+    def step_wait(self):
+        return self.step(self._actions)
+
+    def step(self, actions: np.ndarray, noise: Optional[np.ndarray] = None, extras: bool = False):
+        """
+        One step of every env through the host-pointer entry point (dockauv_step_host).
+        Returns (obs [N, n_obs] float32, reward [N], done [N] bool, infos).
+        """
+        a = np.ascontiguousarray(actions, dtype=self._np_t).reshape(self.num_envs, self.n_u)
+        w = None if noise is None else np.ascontiguousarray(noise, dtype=self._np_t).reshape(self.num_envs)
+        self._io_keepalive = (a, w)
+        io = self._io(a, w, extras)
+        rc = self._lib.dockauv_step_host(self._handle, C.byref(io))
+        _capi.check(self._lib, self._handle, rc, "dockauv_step_host")
+        self.t_total_steps += 1
+        self._steps_since_reset += 1
+        done = self._done.astype(bool)
+        infos: List[dict] = [{} for _ in range(self.num_envs)]
+        didx = np.flatnonzero(done)
+        for i in didx:
+            cond = int(self._cond[i])
+            cidx = [k for k in range(5) if cond >> k & 1]
+            infos[i] = {"conditions_true": cidx, "conditions_true_info": [META_DATA_DONE[k] for k in cidx],
+                        "collision": bool(cond & 16), "goal_reached": bool(cond & 1), "done": True,
+                        "episode_number": int(self.episode[i])}
+            if self.auto_reset:
+                infos[i]["terminal_observation"] = self._termobs[i].copy()
+        if self.auto_reset and didx.size:
+            if self.rng_mode == "per_env":
+                # parity mode: the kernel reset these envs from a placeholder; overwrite with the episode the
+                # reference would have drawn now (stream burned by the elapsed steps), then restage the pool
+                self.reset_envs_in_place(didx)
+            else:
+                self.load_episodes(didx, self.generate_episodes(didx), pool=True)
+            self.episode[didx] += 1
+        return self._obs.copy(), self._rew.copy(), done, infos
+
+    def reset_envs_in_place(self, idx: np.ndarray) -> None:
+        ep = self.generate_episodes(idx)
+        self.load_episodes(idx, ep)
+
+    # extras of the last step (parity tests, logging): last_reward_arr, conditions, nav errors, ray distances
+    @property
+    def last_reward_arr(self) -> np.ndarray:
+        return self._terms
+
+    @property
+    def conditions(self) -> np.ndarray:
+        return (self._cond[:, None] >> np.arange(5)[None, :] & 1).astype(bool)
+
+    @property
+    def nav_errors(self) -> np.ndarray:
+        return self._nav
+
+    @property
+    def intersec_dist(self) -> np.ndarray:
+        return self._ray
+
+    # ------------------------------------------------------------------------------------------ device-pointer path
+    def step_device(self, actions_ptr: int, obs_ptr: int, reward_ptr: int, done_ptr: int, stream: int = 0,
+                    noise_ptr: int = 0, terminal_obs_ptr: int = 0, conditions_ptr: int = 0) -> None:
+        """Asynchronous step on device pointers (torch tensors' data_ptr()): no host copies, no sync."""
+        io = _capi.StepIO()
+        io.actions, io.obs, io.reward, io.done = actions_ptr, obs_ptr, reward_ptr, done_ptr
+        io.noise = noise_ptr or None
+        io.terminal_obs = terminal_obs_ptr or None
+        io.conditions = conditions_ptr or None
+        rc = self._lib.dockauv_step(self._handle, C.byref(io), C.c_void_p(stream or None))
+        _capi.check(self._lib, self._handle, rc, "dockauv_step")
+
+    def time_steps_device(self, actions_ptr: int, obs_ptr: int, reward_ptr: int, done_ptr: int, steps: int,
+                          stream: int = 0) -> float:
+        """Average per-launch time in microseconds from HIP events on `stream` (bench.py)."""
+        io = _capi.StepIO()
+        io.actions, io.obs, io.reward, io.done = actions_ptr, obs_ptr, reward_ptr, done_ptr
+        out = C.c_double(0.0)
+        rc = self._lib.dockauv_time_steps(self._handle, C.byref(io), C.c_void_p(stream or None), int(steps), C.byref(out))
+        _capi.check(self._lib, self._handle, rc, "dockauv_time_steps")
+        return out.value
+
+    def synchronize(self) -> None:
+        _capi.check(self._lib, self._handle, self._lib.dockauv_synchronize(self._handle), "dockauv_synchronize")
+
+    # ------------------------------------------------------------------------------------------ VecEnv odds and ends
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.dockauv_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def get_attr(self, attr_name, indices=None):
+        n = self.num_envs if indices is None else len(np.atleast_1d(indices))
+        return [getattr(self, attr_name)] * n
+
+    def set_attr(self, attr_name, value, indices=None):
+        setattr(self, attr_name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        return [getattr(self, method_name)(*args, **kwargs)]
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self.num_envs
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering is outside the accelerated path (reference: utils/plotutils.py)")

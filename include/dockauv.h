@@ -1,0 +1,204 @@
+/*
+ * dockauv.h -- C ABI of libdockauv.so: batched docking3d step() on MI355X (gfx950).
+ *
+ * The reference (Erikx3/gym_dockauv) is pure Python and has no FFI; the boundary it offers is the Python class
+ * API of gym_dockauv/envs/docking3d.py.  This header is the C-ABI a maintainer would bind underneath that API
+ * (ctypes stub: INTEGRATION.md).  Each entry point names the reference interface it replaces.
+ *
+ * Conventions: every function returns 0 on success and a negative DOCKAUV_E_* code on failure;
+ * dockauv_last_error() gives the message.  No exceptions cross the boundary.  All pointers are plain C pointers
+ * with explicit sizes; no torch / numpy types.  One host thread drives one handle; work is stream-ordered on the
+ * HIP stream passed to dockauv_step (NULL = the default stream).  The library owns the per-env state in HBM until
+ * dockauv_destroy; the caller owns every buffer it passes in.
+ *
+ * Host-side field I/O (dockauv_set_field / dockauv_get_field) is always float64, row-major [count][width]
+ * ("array of envs"); the library converts to its struct-of-arrays device layout and device precision.
+ */
+#ifndef DOCKAUV_H
+#define DOCKAUV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DOCKAUV_ABI_VERSION 1
+#define DOCKAUV_MAX_U 8          /* inputs: BlueROV2 joystick 6, BlueROV2 direct 8, LAUV 3 */
+#define DOCKAUV_N_REWARDS 13     /* envs/docking3d.py:152 */
+#define DOCKAUV_N_CONDITIONS 5   /* envs/docking3d.py:597-619 */
+#define DOCKAUV_N_OBS_BASE 16    /* envs/docking3d.py:114 */
+#define DOCKAUV_MAX_RAYS 1024
+#define DOCKAUV_MAX_CAPSULES 8
+#define DOCKAUV_MAX_SPHERES 16
+
+/* error codes */
+#define DOCKAUV_OK 0
+#define DOCKAUV_E_INVALID (-1)   /* bad argument / config */
+#define DOCKAUV_E_HIP (-2)       /* HIP runtime error (message has hipGetErrorString) */
+#define DOCKAUV_E_NODEVICE (-3)  /* no usable gfx950 device */
+#define DOCKAUV_E_RANGE (-4)     /* first/count outside [0, n_envs) */
+
+/* device arithmetic type of the path */
+#define DOCKAUV_F32 0            /* product path ("within 1e-5 of the float64 reference") */
+#define DOCKAUV_F64 1            /* validation path: same kernels instantiated in double */
+
+/* vehicle model kinds */
+#define DOCKAUV_VEH_CONSTB 0     /* constant B, diagonal damping: objects/vehicles/BlueROV2.py:27-88 */
+#define DOCKAUV_VEH_LAUV 1       /* B(nu) ~ u^2, cross-coupled damping + lift: objects/vehicles/LAUV.py:59-110 */
+
+/* what happens to an env whose episode ended inside dockauv_step */
+#define DOCKAUV_RESET_NONE 0     /* nothing: caller resets (single-env gym.Env semantics, docking3d.py:222) */
+#define DOCKAUV_RESET_POOL 1     /* in-kernel reset from the host-staged next-episode pool (VecEnv auto-reset) */
+#define DOCKAUV_RESET_DEVICE 2   /* in-kernel scenario generation with a counter RNG (throughput mode) */
+
+/* scenario ids for DOCKAUV_RESET_DEVICE (envs/docking3d.py:795-988) */
+#define DOCKAUV_SCN_SIMPLE 0
+#define DOCKAUV_SCN_SIMPLE_CURRENT 1
+#define DOCKAUV_SCN_CAPSULE 2
+#define DOCKAUV_SCN_CAPSULE_CURRENT 3
+#define DOCKAUV_SCN_OBSTACLES 4
+#define DOCKAUV_SCN_OBSTACLES_NOCAP 5
+#define DOCKAUV_SCN_OBSTACLES_CURRENT 6
+#define DOCKAUV_SCN_SPHERES 7    /* build-defined: SimpleDocking3d + max_spheres spheres in a 3..12 m shell */
+
+/*
+ * One vehicle type.  Replaces the per-instance constants of objects/statespace.py:58-197 (StateSpace) and the
+ * B / D / u_bound overrides of the two vehicle classes.  The host computes M_inv exactly like the reference
+ * (numpy.linalg.inv of M_RB + M_A in float64, statespace.py:190-197) and hands the numbers over.
+ */
+typedef struct dockauv_vehicle {
+    int32_t kind;                 /* DOCKAUV_VEH_* */
+    int32_t n_u;                  /* number of inputs, <= DOCKAUV_MAX_U */
+    double m;                     /* mass */
+    double W, BY;                 /* weight m*g (statespace.py:86-88), buoyancy */
+    double r_G[3], r_B[3];        /* CG / CB offsets from CO */
+    double I_b[9];                /* inertia about CO, row-major (statespace.py:105-117) */
+    double ma_diag[6];            /* diagonal of M_A = -(X_udot..N_rdot) (statespace.py:164-187) */
+    double d_lin[6], d_quad[6];   /* X_u..N_r, X_uu..N_rr (statespace.py:288-351) */
+    double M_inv[36];             /* row-major */
+    double B[6 * DOCKAUV_MAX_U];  /* row-major 6 x DOCKAUV_MAX_U, constant-B kinds only (BlueROV2.py:34-72) */
+    double u_lo[DOCKAUV_MAX_U], u_hi[DOCKAUV_MAX_U]; /* u_bound columns (BlueROV2.py:44-50, LAUV.py:103-110) */
+    /* LAUV extras (LAUV.py:32-55), order: Y_r Y_rr Y_urf | Z_q Z_qq Z_uqf | M_w M_ww M_uwb+M_uwf |
+       N_v N_vv N_uvb+N_uvf | Y_uvb+Y_uvf  Z_uwb+Z_uwf  M_uqf  N_urf | Y_uudr Z_uuds M_uuds N_uudr */
+    double lauv[20];
+} dockauv_vehicle;
+
+/*
+ * Environment batch configuration.  Replaces the reads of the config dict in BaseDocking3d.__init__
+ * (envs/docking3d.py:48-220; key schema config/env_config.py:20-91) and Radar.__init__ (objects/sensor.py:43-87).
+ */
+typedef struct dockauv_config {
+    uint32_t struct_size;          /* sizeof(dockauv_config): ABI check */
+    uint32_t abi_version;          /* DOCKAUV_ABI_VERSION */
+    int32_t n_envs;                /* envs owned by this handle (this GPU's shard) */
+    int32_t precision;             /* DOCKAUV_F32 / DOCKAUV_F64 */
+    int32_t n_vehicles;            /* 1, or 2 for a per-env vehicle id (mixed batch) */
+    int32_t reset_mode;            /* DOCKAUV_RESET_* */
+    int32_t scenario;              /* DOCKAUV_SCN_* (used by DOCKAUV_RESET_DEVICE only) */
+    int32_t max_timesteps;         /* "max_timesteps" */
+    int32_t reward_set;            /* "reward_set": 1 or 2 (docking3d.py:519-582) */
+    int32_t max_capsules;          /* per-env capsule slots, 0..DOCKAUV_MAX_CAPSULES */
+    int32_t max_spheres;           /* per-env sphere slots, 0..DOCKAUV_MAX_SPHERES */
+    int32_t n_v, n_h;              /* ray fan: vertical x horizontal rays (sensor.py:56-63) */
+    int32_t blocksize_reduce;      /* "blocksize_reduce" (sensor.py:136-137) */
+    int32_t envs_per_group;        /* launch tuning: 0 = auto */
+    int32_t threads_per_group;     /* launch tuning: 0 = auto */
+    uint64_t seed;                 /* DOCKAUV_RESET_DEVICE: counter-RNG key */
+    double t_step_size;            /* "t_step_size" */
+    double lowpass_T1;             /* 0.2 (objects/auvsim.py:40) */
+    double current_mu;             /* Gauss-Markov mu, 0.005 in every shipped scenario (docking3d.py:820) */
+    double max_dist_from_goal, max_attitude, dist_goal_reached_tol;
+    double vel_max[6];             /* u_max v_max w_max p_max q_max r_max */
+    double safety_radius;          /* 1.0, hard-wired in the reference (objects/auvsim.py:43) */
+    double w_d, w_delta_theta, w_delta_psi, w_phi, w_theta, w_Thetadot, w_oa; /* "reward_factors" */
+    double w_done[DOCKAUV_N_CONDITIONS];  /* w_goal w_deltad_max w_Theta_max w_t_max w_col (docking3d.py:181-187) */
+    double action_reward_factors[DOCKAUV_MAX_U]; /* scalar config value broadcast by the host (docking3d.py:584) */
+    double radar_max_dist;         /* "radar.max_dist" */
+    double radar_alpha_max, radar_beta_max; /* alpha/2, beta/2 (sensor.py:53-54) */
+    /* [n_v*n_h][4] row-major, ray index = iv*n_h + ih: unit body-frame direction normalise(1, sin beta, sin alpha)
+     * (sensor.py:66-71) and the obstacle-avoidance weight beta_oa (docking3d.py:786-788).  Read during create only. */
+    const double* ray_table;
+    dockauv_vehicle vehicle[2];
+} dockauv_config;
+
+typedef struct dockauv_env_s* dockauv_handle;
+
+/* per-env fields addressable from the host (width = doubles per env) */
+#define DOCKAUV_F_STATE 0        /* 12: eta(6), nu_r(6)                       (objects/auvsim.py:37,162-246) */
+#define DOCKAUV_F_U 1            /* DOCKAUV_MAX_U: filtered input u           (objects/auvsim.py:277-284) */
+#define DOCKAUV_F_GOAL 2         /* 4: goal x y z, heading_goal_reached       (docking3d.py:194,202) */
+#define DOCKAUV_F_CURRENT 3      /* 5: V_c V_min V_max alpha beta             (objects/current.py:20-31) */
+#define DOCKAUV_F_TSTEPS 4       /* 1: steps in this episode                  (docking3d.py:139) */
+#define DOCKAUV_F_CAPSULES 5     /* max_capsules*7: bot xyz, top xyz, radius (radius <= 0: unused slot) */
+#define DOCKAUV_F_SPHERES 6      /* max_spheres*4: centre xyz, radius (radius <= 0: unused slot) */
+#define DOCKAUV_F_VEHICLE_ID 7   /* 1: index into config.vehicle[] (mixed batches) */
+#define DOCKAUV_F_CUM_REWARD 8   /* 1: cumulative reward of the running episode (docking3d.py:156) */
+#define DOCKAUV_F_EPISODE 9      /* 1: episode counter (docking3d.py:141) */
+/* next-episode pool (DOCKAUV_RESET_POOL): same layouts */
+#define DOCKAUV_F_POOL_POSE 16       /* 6: position, attitude */
+#define DOCKAUV_F_POOL_GOAL 17       /* 4 */
+#define DOCKAUV_F_POOL_CURRENT 18    /* 5 */
+#define DOCKAUV_F_POOL_CAPSULES 19   /* max_capsules*7 */
+#define DOCKAUV_F_POOL_SPHERES 20    /* max_spheres*4 */
+
+/*
+ * Inputs / outputs of one step.  Replaces the arguments and return tuple of BaseDocking3d.step
+ * (envs/docking3d.py:346-402) for a batch.  "T" = float (DOCKAUV_F32) or double (DOCKAUV_F64).
+ * In dockauv_step every pointer is a DEVICE pointer; in dockauv_step_host every pointer is a HOST pointer.
+ * Nullable members may be NULL.
+ */
+typedef struct dockauv_step_io {
+    const void* actions;     /* T [n_envs][n_u_max] row-major, raw policy output (clipped inside, auvsim.py:74) */
+    const void* noise;       /* nullable, T [n_envs]: w_k ~ N(0, sigma) of Current.sim (current.py:88); NULL = 0 */
+    float* obs;              /* float32 [n_envs][n_obs] row-major (docking3d.py:462-488) */
+    void* reward;            /* T [n_envs] (docking3d.py:593) */
+    uint8_t* done;           /* [n_envs] 0/1 (docking3d.py:630) */
+    void* reward_terms;      /* nullable, T [n_envs][13]: last_reward_arr (docking3d.py:513-588) */
+    uint8_t* conditions;     /* nullable, [n_envs]: bit i = condition i (docking3d.py:608-619) */
+    void* nav;               /* nullable, T [n_envs][4]: delta_d, delta_theta, delta_psi, delta_heading_goal */
+    void* ray_dist;          /* nullable, T [n_envs][n_rays]: clamped intersec_dist (sensor.py:113-118) */
+    float* terminal_obs;     /* nullable, float32 [n_envs][n_obs]: written only where done (auto-reset modes) */
+} dockauv_step_io;
+
+/* library / build info; callable without a GPU */
+int dockauv_abi_version(void);
+const char* dockauv_build_info(void);
+/* message of the last failure on this handle (h may be NULL: last failure of create) */
+const char* dockauv_last_error(dockauv_handle h);
+
+/* BaseDocking3d.__init__ (docking3d.py:48-220) for a batch: allocates the SoA state in HBM of `device` */
+int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out);
+int dockauv_destroy(dockauv_handle h);
+
+/* derived sizes: n_obs = 16 + n_rays_reduced (docking3d.py:114-115), n_rays (sensor.py:63), n_u_max */
+int dockauv_n_obs(dockauv_handle h);
+int dockauv_n_rays(dockauv_handle h);
+int dockauv_n_u(dockauv_handle h);
+
+/* state access: auv.state / position / attitude setters, goal_location, Current(...), capsules, spheres
+ * (docking3d.py:803-988 generate_environment; objects/auvsim.py:174-195).  src/dst: double [count][width]. */
+int dockauv_field_width(dockauv_handle h, int field);
+int dockauv_set_field(dockauv_handle h, int field, int first, int count, const double* src);
+int dockauv_get_field(dockauv_handle h, int field, int first, int count, double* dst);
+
+/* AUVSim.reset + counters of BaseDocking3d.reset (objects/auvsim.py:55-65, docking3d.py:262-276) for envs
+ * [first, first+count): state, u, t_steps, cumulative reward -> 0; episode += 1.  Pose/goal/... are then set
+ * with dockauv_set_field. */
+int dockauv_reset_envs(dockauv_handle h, int first, int count);
+
+/* BaseDocking3d.step (docking3d.py:346-402) for all envs of the handle; device pointers, asynchronous on stream */
+int dockauv_step(dockauv_handle h, const dockauv_step_io* io, void* hip_stream);
+/* same with host pointers (staged through the library's pinned buffers; synchronous) */
+int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io);
+/* block until everything queued on the handle's last-used stream is done */
+int dockauv_synchronize(dockauv_handle h);
+
+/* measurement helpers (bench.py): run `steps` step launches back-to-back on `stream` re-using the same io,
+ * bracketed by HIP events ON THAT STREAM; returns the average per-launch time in microseconds. */
+int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_stream, int steps, double* avg_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOCKAUV_H */

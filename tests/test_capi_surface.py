@@ -1,0 +1,80 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/dockauv.h declares, the ctypes
+struct mirrors the C struct, and creating a handle without a GPU fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "dockauv.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from gym_dockauv_amd.csrc import build
+    build.build()
+    from gym_dockauv_amd import _capi
+    return _capi.load_library()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dockauv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    from gym_dockauv_amd import _capi
+    names = declared_symbols()
+    assert len(names) >= 15
+    bound = {s[0] for s in _capi.SYMBOLS}
+    assert set(names) == bound, f"binding and header disagree: {set(names) ^ bound}"
+    for n in names:
+        assert hasattr(lib, n), f"{n} not exported by libdockauv.so"
+    assert lib.dockauv_abi_version() == _capi.ABI_VERSION
+    assert b"gfx950" in lib.dockauv_build_info()
+
+
+def test_struct_layout_matches_c(tmp_path):
+    """Compile a tiny C program against the header and compare sizeof/offsetof with the ctypes mirror."""
+    from gym_dockauv_amd import _capi
+    src = tmp_path / "layout.c"
+    src.write_text(f'''
+#include <stdio.h>
+#include <stddef.h>
+#include "{HEADER}"
+int main(void) {{
+  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dockauv_config), sizeof(dockauv_vehicle), sizeof(dockauv_step_io),
+         offsetof(dockauv_config, seed), offsetof(dockauv_config, ray_table), offsetof(dockauv_config, vehicle),
+         offsetof(dockauv_vehicle, lauv));
+  return 0;
+}}''')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    got = [C.sizeof(_capi.Config), C.sizeof(_capi.Vehicle), C.sizeof(_capi.StepIO), _capi.Config.seed.offset,
+           _capi.Config.ray_table.offset, _capi.Config.vehicle.offset, _capi.Vehicle.lauv.offset]
+    assert [int(x) for x in out] == got
+
+
+def test_create_without_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    from gym_dockauv_amd import _capi
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    with pytest.raises(_capi.DockAUVError) as ei:
+        BatchedDocking3d(num_envs=4)
+    assert "no CPU fallback" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_bad_config_rejected(lib):
+    from gym_dockauv_amd import _capi
+    cfg = _capi.Config()
+    cfg.struct_size = 1
+    h = C.c_void_p()
+    rc = lib.dockauv_create(C.byref(cfg), 0, C.byref(h))
+    assert rc == -1 and b"mismatch" in lib.dockauv_last_error(None)
