@@ -360,11 +360,11 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
         for (int v = 0; v < c.n_vehicles; ++v) fill_vehicle(h->a32.V[v], c.vehicle[v]);
         h->a32.B = B;
     }
-    // the dynamic-LDS request must fit the 160 KiB of a gfx950 CU (64 KiB without opting in)
+    // the dynamic-LDS request must fit the 160 KiB of a gfx950 CU
     size_t lds = h->f64 ? lds_bytes<double>(64, c.max_capsules, c.max_spheres, h->n_rays, h->n_obs, h->has_rays)
                         : lds_bytes<float>(64, c.max_capsules, c.max_spheres, h->n_rays, h->n_obs, h->has_rays);
-    if (lds > 64 * 1024) {
-        fail(nullptr, DOCKAUV_E_INVALID, "configuration needs %zu B of LDS per group (> 64 KiB): fewer rays/obstacles", lds);
+    if (lds > 160 * 1024) {
+        fail(nullptr, DOCKAUV_E_INVALID, "configuration needs %zu B of LDS per group (> 160 KiB): fewer rays/obstacles", lds);
         dockauv_destroy(h);
         return DOCKAUV_E_INVALID;
     }

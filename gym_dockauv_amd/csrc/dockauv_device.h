@@ -94,8 +94,8 @@ struct KernelArgs {
 };
 
 // LDS hand-over layout between the env phase and the ray stage
-constexpr int kCapFields = 14;   // ba(3) oa(3) oc2(3) baba baoa cc c2b c2t   (objects/shape.py:341-363)
-constexpr int kSphFields = 4;    // oc(3) |oc|^2 - r^2
+constexpr int kCapFields = 10;   // unit axis d(3), oa_perp(3), oa_par, |ba|, |oa_perp|^2 - r^2, r^2
+constexpr int kSphFields = 4;    // oc(3), r^2
 constexpr int kPoseFields = 14;  // pos(3) R(9) n_cap n_sph
 
 template <typename T>

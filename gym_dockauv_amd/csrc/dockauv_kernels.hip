@@ -263,36 +263,43 @@ __device__ __forceinline__ void vehicle_step_(const VehicleP<T>& V, const EnvP<T
 // (field counts and lds_bytes live in dockauv_device.h, shared with the host side)
 
 // ------------------------------------------------------------------------------------------ ray kernels
-// one ray vs one capsule with the case structure of the vectorised reference routine (objects/shape.py:327-390)
+// One ray vs one capsule: same case structure and same results as the vectorised reference routine
+// (objects/shape.py:327-390), but evaluated in a form that is well conditioned in float32.  The reference works with
+// the un-normalised axis ba and the products baba*oaoa - baoa^2, b^2 - a*c (40 m pillars: terms ~1e6, catastrophic
+// cancellation in fp32).  With the unit axis d = ba/|ba| and components perpendicular to it,
+//   a = |rd_perp|^2, b = rd . oa_perp, c = |oa_perp|^2 - r^2   (reference a, b, c divided by baba),
+// t = (-b - sqrt(b^2 - a c)) / a and y/|ba| = oa_par + t (rd . d) are unchanged.  Cap spheres use
+// h2 = r^2 - |oc - (rd . oc) rd|^2 (= b2^2 - c2 for unit rd).
+// LDS record: d(3) oa_perp(3) oa_par len c r2
 template <typename T>
 __device__ __forceinline__ T ray_capsule_(const T* __restrict__ cp, int stride, T rx, T ry, T rz) {
-    const T bax = cp[0 * stride], bay = cp[1 * stride], baz = cp[2 * stride];
-    const T oax = cp[3 * stride], oay = cp[4 * stride], oaz = cp[5 * stride];
-    const T baba = cp[9 * stride], baoa = cp[10 * stride], cc = cp[11 * stride];
-    const T bard = rx * bax + ry * bay + rz * baz;
-    const T rdoa = rx * oax + ry * oay + rz * oaz;
-    const T a = baba - bard * bard;
-    const T b = baba * rdoa - baoa * bard;
+    const T dx = cp[0 * stride], dy = cp[1 * stride], dz = cp[2 * stride];
+    const T px = cp[3 * stride], py = cp[4 * stride], pz = cp[5 * stride];
+    const T oa_par = cp[6 * stride], len = cp[7 * stride], cc = cp[8 * stride], r2 = cp[9 * stride];
+    const T bard = rx * dx + ry * dy + rz * dz;
+    const T qx = rx - bard * dx, qy = ry - bard * dy, qz = rz - bard * dz;   // rd_perp
+    const T a = qx * qx + qy * qy + qz * qz;
+    const T b = rx * px + ry * py + rz * pz;
     const T hh = b * b - a * cc;
     T res = -inf_<T>();
     if (hh > T(0)) {   // h <= 0 (tangent included) and NaN -> -inf  (shape.py:389)
         const T t = (-b - sqrt_(hh)) / a;
-        const T y = baoa + t * bard;
-        if (y > T(0) && y < baba) {
+        const T y = oa_par + t * bard;
+        if (y > T(0) && y < len) {
             res = t;
         } else {
-            T ocx, ocy, ocz, c2;
+            T ocx, ocy, ocz, rr = r2;
             if (y >= T(0)) {         // top cap wins at y == 0 (second assignment, shape.py:378-379)
-                ocx = cp[6 * stride]; ocy = cp[7 * stride]; ocz = cp[8 * stride]; c2 = cp[13 * stride];
+                const T s = oa_par - len;
+                ocx = px + s * dx; ocy = py + s * dy; ocz = pz + s * dz;
             } else if (y <= T(0)) {
-                ocx = oax; ocy = oay; ocz = oaz; c2 = cp[12 * stride];
+                ocx = px + oa_par * dx; ocy = py + oa_par * dy; ocz = pz + oa_par * dz;
             } else {                 // y is NaN: oc stays the zero vector (shape.py:377)
                 ocx = ocy = ocz = T(0);
-                // c2 = 0 - r^2 ; c2b = oaoa - r^2  => r^2 = oaoa - c2b
-                c2 = cp[12 * stride] - (oax * oax + oay * oay + oaz * oaz);
             }
             const T b2 = rx * ocx + ry * ocy + rz * ocz;
-            const T h2 = b2 * b2 - c2;
+            const T ex = ocx - b2 * rx, ey = ocy - b2 * ry, ez = ocz - b2 * rz;
+            const T h2 = rr - (ex * ex + ey * ey + ez * ez);
             res = (h2 > T(0)) ? (-b2 - sqrt_(h2)) : T(0);
         }
         if (res == T(0)) res = -inf_<T>();
@@ -416,21 +423,20 @@ __global__ __launch_bounds__(NT) void step_kernel(const KernelArgs<T, 2> A) {
                     const T oax = st[0] - c1x, oay = st[1] - c1y, oaz = st[2] - c1z;
                     const T ocx = st[0] - c2x, ocy = st[1] - c2y, ocz = st[2] - c2z;
                     const T baba = bax * bax + bay * bay + baz * baz;
-                    const T baoa = bax * oax + bay * oay + baz * oaz;
-                    const T oaoa = oax * oax + oay * oay + oaz * oaz;
-                    T* cp = lds_cap + (size_t)c * kCapFields * EPG + tid;
-                    cp[0 * EPG] = bax; cp[1 * EPG] = bay; cp[2 * EPG] = baz;
-                    cp[3 * EPG] = oax; cp[4 * EPG] = oay; cp[5 * EPG] = oaz;
-                    cp[6 * EPG] = ocx; cp[7 * EPG] = ocy; cp[8 * EPG] = ocz;
-                    cp[9 * EPG] = baba;
-                    cp[10 * EPG] = baoa;
-                    cp[11 * EPG] = baba * oaoa - baoa * baoa - rad * rad * baba;
-                    cp[12 * EPG] = oaoa - rad * rad;
-                    cp[13 * EPG] = ocx * ocx + ocy * ocy + ocz * ocz - rad * rad;
-                    // collision_capsule_sphere / dist_line_point (objects/shape.py:195-210, 393-417)
-                    const T inv_len = T(1) / sqrt_(baba);
+                    const T len = sqrt_(baba);
+                    const T inv_len = T(1) / len;
                     const T dx = bax * inv_len, dy = bay * inv_len, dz = baz * inv_len;
-                    const T s = -(oax * dx + oay * dy + oaz * dz);
+                    const T oa_par = oax * dx + oay * dy + oaz * dz;
+                    const T px = oax - oa_par * dx, py = oay - oa_par * dy, pz = oaz - oa_par * dz;
+                    T* cp = lds_cap + (size_t)c * kCapFields * EPG + tid;
+                    cp[0 * EPG] = dx; cp[1 * EPG] = dy; cp[2 * EPG] = dz;
+                    cp[3 * EPG] = px; cp[4 * EPG] = py; cp[5 * EPG] = pz;
+                    cp[6 * EPG] = oa_par;
+                    cp[7 * EPG] = len;
+                    cp[8 * EPG] = px * px + py * py + pz * pz - rad * rad;
+                    cp[9 * EPG] = rad * rad;
+                    // collision_capsule_sphere / dist_line_point (objects/shape.py:195-210, 393-417)
+                    const T s = -oa_par;
                     const T t = ocx * dx + ocy * dy + ocz * dz;
                     T hh = s > t ? s : t;
                     hh = hh > T(0) ? hh : T(0);
@@ -451,7 +457,7 @@ __global__ __launch_bounds__(NT) void step_kernel(const KernelArgs<T, 2> A) {
                     const T d2 = ocx * ocx + ocy * ocy + ocz * ocz;
                     T* sp = lds_sph + (size_t)s * kSphFields * EPG + tid;
                     sp[0 * EPG] = ocx; sp[1 * EPG] = ocy; sp[2 * EPG] = ocz;
-                    sp[3 * EPG] = d2 - rad * rad;
+                    sp[3 * EPG] = rad * rad;
                     // collision_sphere_spheres (objects/shape.py:182-192)
                     collision = collision || (sqrt_(d2) <= E.safety + rad);
                 }
@@ -492,8 +498,11 @@ __global__ __launch_bounds__(NT) void step_kernel(const KernelArgs<T, 2> A) {
                 T sbest = inf_<T>(), sfirst = T(0);
                 for (int s = 0; s < nsph; ++s) {
                     const T* sp = lds_sph + (size_t)s * kSphFields * EPG + e;
-                    const T b = sp[0 * EPG] * rx + sp[1 * EPG] * ry + sp[2 * EPG] * rz;
-                    const T hh = b * b - sp[3 * EPG];
+                    // h = b^2 - (|oc|^2 - r^2) evaluated as r^2 - |oc - b rd|^2 (no cancellation far from the sphere)
+                    const T ox = sp[0 * EPG], oy = sp[1 * EPG], oz = sp[2 * EPG];
+                    const T b = ox * rx + oy * ry + oz * rz;
+                    const T ex = ox - b * rx, ey = oy - b * ry, ez = oz - b * rz;
+                    const T hh = sp[3 * EPG] - (ex * ex + ey * ey + ez * ez);
                     const T v = (hh < T(0)) ? -inf_<T>() : (-b - sqrt_(hh));
                     if (s == 0) sfirst = v;
                     if (v > T(0) && v < sbest) sbest = v;
@@ -719,6 +728,16 @@ template <typename T, int VK, bool RAYS, int EPG, int NT>
 static int launch_one(const KernelArgs<T, 2>& a, void* stream) {
     const int groups = (a.E.n_envs + EPG - 1) / EPG;
     const size_t lds = lds_bytes<T>(EPG, a.E.max_cap, a.E.max_sph, a.E.n_rays, a.E.n_obs, RAYS);
+    if (lds > 64 * 1024) {
+        // gfx950 has 160 KiB of LDS per CU; more than 64 KiB per group must be requested explicitly
+        static size_t granted = 0;
+        if (lds > granted) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<T, VK, RAYS, EPG, NT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            granted = lds;
+        }
+    }
     hipLaunchKernelGGL((step_kernel<T, VK, RAYS, EPG, NT>), dim3(groups), dim3(NT), lds, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
