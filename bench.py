@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""
+bench.py -- env-steps/s of the batched docking3d step() on N MI355X (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W                       (defaults finish in about a minute)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+A "step" is one launch of the fused HIP step kernel over this rank's envs (weak scaling: the per-GPU env count is
+fixed), followed -- for N > 1 -- by one RCCL all-gather of [obs | reward | done] over xGMI so that a single learner
+sees all observations.  Inputs (actions) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Workloads (--config):
+  2  BlueROV2, SimpleDocking3d, 4 096 envs/GPU, no obstacles (pure 6-DOF RKF45 + reward)      [default]
+  3  BlueROV2, 16-beam fan vs 8 spheres, 65 536 envs/GPU
+  4  LAUV, ObstaclesDocking3d (5 capsules, 63 rays), t_step_size 0.02, 32 768 envs/GPU
+  5  BlueROV2/LAUV 50/50, ObstaclesCurrentDocking3d, t_step_size 0.02, 65 536 envs/GPU
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES = {2: 356, 3: 420, 4: 460, 5: 482}   # algorithmic bytes per env-step
+HBM_PEAK_GBPS = 8000.0                           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def workload(config_id: int, envs: int):
+    from gym_dockauv_amd.config.env_config import BASE_CONFIG
+    cfg = copy.deepcopy(BASE_CONFIG)
+    fan16 = {"alpha": 30 * np.pi / 180, "beta": 30 * np.pi / 180, "ray_per_deg": 10 * np.pi / 180}
+    if config_id == 2:
+        return dict(cfg=cfg, scenario="SimpleDocking3d", envs=envs or 4096, vehicles=None,
+                    name="config2: BlueROV2 SimpleDocking3d, no sensors, h=0.1")
+    if config_id == 3:
+        cfg["radar"].update(fan16)
+        return dict(cfg=cfg, scenario="SphereDocking3d", envs=envs or 65536, vehicles=None,
+                    name="config3: BlueROV2 + 16-beam fan vs 8 spheres, h=0.1")
+    if config_id == 4:
+        cfg["vehicle"] = "LAUV"
+        cfg["t_step_size"] = 0.02
+        return dict(cfg=cfg, scenario="ObstaclesDocking3d", envs=envs or 32768, vehicles=None,
+                    name="config4: LAUV ObstaclesDocking3d (5 capsules, 63 rays), h=0.02")
+    if config_id == 5:
+        cfg["t_step_size"] = 0.02
+        n = envs or 65536
+        return dict(cfg=cfg, scenario="ObstaclesCurrentDocking3d", envs=n,
+                    vehicles=["BlueROV2" if i % 2 == 0 else "LAUV" for i in range(n)],
+                    name="config5: BlueROV2/LAUV interleaved, ObstaclesCurrentDocking3d, h=0.02")
+    raise SystemExit(f"unknown --config {config_id}")
+
+
+def cpu_baseline(wl, seconds: float):
+    """The NumPy oracle (a port of the reference's per-env NumPy path) timed on this host, one core, on a bounded
+    sample of the same workload.  Reported next to the GPU number; it is NOT on the product path."""
+    from oracle import dockauv_oracle as orc
+    scenario = wl["scenario"] if wl["scenario"] in orc.SCENARIOS else "SimpleDocking3d"
+    veh = wl["cfg"]["vehicle"]
+    env = orc.OracleEnv(scenario, {"vehicle": veh, "t_step_size": wl["cfg"]["t_step_size"],
+                                   "radar": {k: wl["cfg"]["radar"][k] for k in ("alpha", "beta", "ray_per_deg", "max_dist")}})
+    env.reset(seed=0)
+    n_u = env.model.n_u
+    rs = np.random.RandomState(1234)
+    for _ in range(50):
+        _, _, d, _ = env.step(rs.uniform(-1, 1, n_u))
+        if d:
+            env.reset()
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(100):
+            _, _, d, _ = env.step(rs.uniform(-1, 1, n_u))
+            if d:
+                env.reset()
+        n += 100
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/dockauv_oracle.py (NumPy, float64, 1 env, 1 core), {n} steps of {scenario}/{veh} "
+                      f"in {dt:.1f} s, uniform random actions, reset on done"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--envs", type=int, default=0, help="envs per GPU (0 = the config's size)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    wl = workload(args.config, args.envs)
+    N = wl["envs"]
+    env = BatchedDocking3d(wl["cfg"], num_envs=N, scenario=wl["scenario"], device=local_rank, precision="f32",
+                           reset_mode="device", device_seed=0x5EED0000 + rank, rng="batched", vehicles=wl["vehicles"],
+                           threads_per_group=args.threads)
+    env._gen = np.random.default_rng(1000 + rank)
+    env.reset()
+    n_obs, n_u = env.n_observations, env.n_u
+
+    # synthetic actions resident in HBM: a ring of distinct batches, uniform in [-1, 1] (counter RNG seeded 1234)
+    RING = 64 if N <= 65536 else 16
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    actions = torch.rand((RING, N, n_u), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
+    # gathered outputs: [world*N, n_obs + 2] would force a strided kernel store; keep three dense buffers and
+    # gather them with one coalesced all-gather each (obs dominates: n_obs*4 B vs 5 B per env)
+    obs_all = torch.zeros((world * N, n_obs), device=dev, dtype=torch.float32)
+    rew_all = torch.zeros((world * N,), device=dev, dtype=torch.float32)
+    done_all = torch.zeros((world * N,), device=dev, dtype=torch.uint8)
+    obs_l, rew_l, done_l = obs_all[rank * N:(rank + 1) * N], rew_all[rank * N:(rank + 1) * N], done_all[rank * N:(rank + 1) * N]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        env.step_device(actions[i % RING].data_ptr(), obs_l.data_ptr(), rew_l.data_ptr(), done_l.data_ptr(), stream=stream)
+        if world > 1:
+            dist.all_gather_into_tensor(obs_all, obs_l)
+            dist.all_gather_into_tensor(rew_all, rew_l)
+            dist.all_gather_into_tensor(done_all, done_l)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # roofline of the dominant (only) kernel: per-dispatch start/stop events on the launch stream
+    k_steps = min(args.steps, 1000)
+    kernel_us = env.time_steps_device(actions[0].data_ptr(), obs_l.data_ptr(), rew_l.data_ptr(), done_l.data_ptr(),
+                                      k_steps, stream=stream)
+    torch.cuda.synchronize()
+    finite = bool(torch.isfinite(obs_all).all().item())
+    n_done = int(done_l.sum().item())
+
+    if rank == 0:
+        bytes_per_launch = ALGO_BYTES[args.config] * N
+        achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"config{args.config}_envs{N}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env-steps/sec (batched docking3d)",
+            "value": world * N * args.steps / dt,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "envs_per_gpu": N, "total_envs": world * N, "n_obs": n_obs, "n_u": n_u,
+                       "auto_reset": "in-kernel scenario generation (Philox4x32-10)", "collective": "rccl all_gather(obs,reward,done)" if world > 1 else "none",
+                       "obs_finite": finite, "done_last_step_rank0": n_done},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "dockauv::step_kernel", "kernel_us": kernel_us,
+                         "algorithmic_bytes_per_env_step": ALGO_BYTES[args.config], "envs_per_launch": N,
+                         "timing": f"hipExtLaunchKernel start/stop events on the launch stream, {k_steps} launches after the timed region"},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

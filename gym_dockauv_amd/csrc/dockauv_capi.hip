@@ -211,14 +211,14 @@ void set_io(StepIO& d, const dockauv_step_io& s) {
     d.terminal_obs = s.terminal_obs;
 }
 
-int launch(dockauv_handle h, const dockauv_step_io* io, hipStream_t stream) {
+int launch(dockauv_handle h, const dockauv_step_io* io, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     int rc;
     if (h->f64) {
         set_io(h->a64.io, *io);
-        rc = launch_step_f64(h->a64, h->vk, h->has_rays, 64, h->threads, stream);
+        rc = launch_step_f64(h->a64, h->vk, h->has_rays, 64, h->threads, stream, ev0, ev1);
     } else {
         set_io(h->a32.io, *io);
-        rc = launch_step_f32(h->a32, h->vk, h->has_rays, 64, h->threads, stream);
+        rc = launch_step_f32(h->a32, h->vk, h->has_rays, 64, h->threads, stream, ev0, ev1);
     }
     if (rc != 0) return fail(h, DOCKAUV_E_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     h->last_stream = stream;
@@ -252,8 +252,13 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
     if (c.n_v <= 0 || c.n_h <= 0 || (long)c.n_v * c.n_h > DOCKAUV_MAX_RAYS) return fail(nullptr, DOCKAUV_E_INVALID, "bad ray fan %d x %d", c.n_v, c.n_h);
     if (c.blocksize_reduce <= 0) return fail(nullptr, DOCKAUV_E_INVALID, "blocksize_reduce must be > 0");
     if (c.reward_set != 1 && c.reward_set != 2) return fail(nullptr, DOCKAUV_E_INVALID, "reward_set must be 1 or 2");
-    if (c.reset_mode < DOCKAUV_RESET_NONE || c.reset_mode > DOCKAUV_RESET_POOL)
+    if (c.reset_mode < DOCKAUV_RESET_NONE || c.reset_mode > DOCKAUV_RESET_DEVICE)
         return fail(nullptr, DOCKAUV_E_INVALID, "reset_mode %d not supported by this build", c.reset_mode);
+    if (c.scenario < DOCKAUV_SCN_SIMPLE || c.scenario > DOCKAUV_SCN_SPHERES) return fail(nullptr, DOCKAUV_E_INVALID, "bad scenario id %d", c.scenario);
+    if (c.reset_mode == DOCKAUV_RESET_DEVICE) {
+        static const int need[8] = {0, 0, 1, 1, 5, 4, 5, 0};
+        if (c.max_capsules < need[c.scenario]) return fail(nullptr, DOCKAUV_E_INVALID, "scenario %d needs %d capsule slots", c.scenario, need[c.scenario]);
+    }
     if (!(c.t_step_size > 0)) return fail(nullptr, DOCKAUV_E_INVALID, "t_step_size must be > 0");
     if (!c.ray_table) return fail(nullptr, DOCKAUV_E_INVALID, "ray_table is NULL");
     for (int v = 0; v < c.n_vehicles; ++v) {
@@ -515,21 +520,24 @@ int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_st
     if (!h || !io || !avg_us || steps <= 0) return fail(h, DOCKAUV_E_INVALID, "bad argument");
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)hip_stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(h, hipEventCreate(&e0));
-    HIP_TRY(h, hipEventCreate(&e1));
-    HIP_TRY(h, hipEventRecord(e0, s));
+    // one start/stop event pair per dispatch, attached to the dispatch itself (hipExtLaunchKernelGGL): the sum of
+    // the elapsed times is pure kernel time on this stream, without launch gaps -- what rocprofv3 --kernel-trace
+    // reports as the kernel's duration.
+    std::vector<hipEvent_t> ev(2 * (size_t)steps);
+    for (auto& e : ev) HIP_TRY(h, hipEventCreate(&e));
     for (int i = 0; i < steps; ++i) {
-        int rc = launch(h, io, s);
+        int rc = launch(h, io, s, ev[2 * i], ev[2 * i + 1]);
         if (rc) return rc;
     }
-    HIP_TRY(h, hipEventRecord(e1, s));
-    HIP_TRY(h, hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    *avg_us = (double)ms * 1000.0 / steps;
+    HIP_TRY(h, hipStreamSynchronize(s));
+    double total_ms = 0.0;
+    for (int i = 0; i < steps; ++i) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        total_ms += ms;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *avg_us = total_ms * 1000.0 / steps;
     return 0;
 }
 

@@ -108,7 +108,10 @@ inline size_t lds_bytes(int epg, int max_cap, int max_sph, int n_rays, int n_obs
 
 // launch one step; implemented in dockauv_kernels.hip.  vk = VehKind, has_rays = obstacles present.
 // returns a hipError_t as int.
-int launch_step_f32(const KernelArgs<float, 2>& a, int vk, bool has_rays, int envs_per_group, int threads, void* stream);
-int launch_step_f64(const KernelArgs<double, 2>& a, int vk, bool has_rays, int envs_per_group, int threads, void* stream);
+// ev0 / ev1: optional hipEvent_t recorded at the start / end of this very dispatch (hipExtLaunchKernelGGL).
+int launch_step_f32(const KernelArgs<float, 2>& a, int vk, bool has_rays, int envs_per_group, int threads, void* stream,
+                    void* ev0 = nullptr, void* ev1 = nullptr);
+int launch_step_f64(const KernelArgs<double, 2>& a, int vk, bool has_rays, int envs_per_group, int threads, void* stream,
+                    void* ev0 = nullptr, void* ev1 = nullptr);
 
 }  // namespace dockauv

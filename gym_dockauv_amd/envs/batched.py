@@ -72,7 +72,8 @@ class BatchedDocking3d:
                  device: int = 0, precision: str = "f32", auto_reset: bool = True, rng: str = "per_env",
                  vehicles: Optional[Sequence[str]] = None, max_capsules: Optional[int] = None,
                  max_spheres: Optional[int] = None, threads_per_group: int = 0,
-                 vehicle_models: Optional[Sequence[VehicleModel]] = None, current_mu: float = scenarios.CURRENT_MU):
+                 vehicle_models: Optional[Sequence[VehicleModel]] = None, current_mu: float = scenarios.CURRENT_MU,
+                 reset_mode: Optional[str] = None, device_seed: int = 0):
         if scenario not in scenarios.SCENARIOS:
             raise KeyError(f"Not valid scenario, available options are {scenarios.SCENARIOS}")
         self.config = copy.deepcopy(env_config)
@@ -80,9 +81,18 @@ class BatchedDocking3d:
         self.num_envs = int(num_envs)
         self.device = int(device)
         self.precision = precision
-        self.auto_reset = bool(auto_reset)
+        # reset_mode: "none" (gym.Env semantics), "pool" (in-kernel reset from host-staged episodes: reference draw
+        # order, parity), "device" (in-kernel scenario generation with a Philox counter RNG: throughput)
+        if reset_mode is None:
+            reset_mode = "pool" if auto_reset else "none"
+        if reset_mode not in ("none", "pool", "device"):
+            raise ValueError("reset_mode must be 'none', 'pool' or 'device'")
+        self.reset_mode = reset_mode
+        self.device_seed = int(device_seed)
+        self.auto_reset = reset_mode != "none"
         self.rng_mode = rng
         self.current_mu = float(current_mu)
+        self.threads_per_group = int(threads_per_group)
         self._lib = _capi.load_library()
         self._np_t = np.float64 if precision == "f64" else np.float32
 
@@ -165,7 +175,7 @@ class BatchedDocking3d:
         cfg.n_envs = self.num_envs
         cfg.precision = _capi.F64 if self.precision == "f64" else _capi.F32
         cfg.n_vehicles = len(self.vehicle_models)
-        cfg.reset_mode = _capi.RESET_POOL if self.auto_reset else _capi.RESET_NONE
+        cfg.reset_mode = {"none": _capi.RESET_NONE, "pool": _capi.RESET_POOL, "device": _capi.RESET_DEVICE}[self.reset_mode]
         cfg.scenario = _capi.SCN[self.scenario]
         cfg.max_timesteps = int(c["max_timesteps"])
         cfg.reward_set = int(c["reward_set"])
@@ -174,8 +184,8 @@ class BatchedDocking3d:
         cfg.n_v, cfg.n_h = self.radar.n_vertical, self.radar.n_horizontal
         cfg.blocksize_reduce = self.radar.blocksize_reduce
         cfg.envs_per_group = 0
-        cfg.threads_per_group = 0
-        cfg.seed = 0
+        cfg.threads_per_group = self.threads_per_group
+        cfg.seed = self.device_seed
         cfg.t_step_size = float(c["t_step_size"])
         cfg.lowpass_T1 = 0.2
         cfg.current_mu = self.current_mu
@@ -330,7 +340,7 @@ class BatchedDocking3d:
         _capi.check(self._lib, self._handle, rc, "dockauv_reset_envs")
         self.load_episodes(idx, self.generate_episodes(idx, reseed=seed is not None or self._seeds is not None))
         self.episode += 1
-        if self.auto_reset:
+        if self.reset_mode == "pool":
             self.load_episodes(idx, self.generate_episodes_for_pool(idx), pool=True)
         obs = np.zeros((self.num_envs, self.n_observations), dtype=np.float32)
         if return_info:
@@ -407,12 +417,14 @@ class BatchedDocking3d:
                         "episode_number": int(self.episode[i])}
             if self.auto_reset:
                 infos[i]["terminal_observation"] = self._termobs[i].copy()
-        if self.auto_reset and didx.size:
+        if self.reset_mode == "device" and didx.size:
+            self.episode[didx] += 1
+        elif self.reset_mode == "pool" and didx.size:
             if self.rng_mode == "per_env":
                 # parity mode: the kernel reset these envs from a placeholder; overwrite with the episode the
                 # reference would have drawn now (stream burned by the elapsed steps), then restage the pool
                 self.reset_envs_in_place(didx)
-            else:
+            elif self.rng_mode == "batched":
                 self.load_episodes(didx, self.generate_episodes(didx), pool=True)
             self.episode[didx] += 1
         return self._obs.copy(), self._rew.copy(), done, infos

@@ -194,8 +194,9 @@ int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io);
 /* block until everything queued on the handle's last-used stream is done */
 int dockauv_synchronize(dockauv_handle h);
 
-/* measurement helpers (bench.py): run `steps` step launches back-to-back on `stream` re-using the same io,
- * bracketed by HIP events ON THAT STREAM; returns the average per-launch time in microseconds. */
+/* measurement helper (bench.py): run `steps` step launches back-to-back on `stream` re-using the same io, each
+ * dispatch carrying its own start/stop HIP events ON THAT STREAM; returns the average KERNEL duration in microseconds
+ * (launch gaps excluded -- comparable with rocprofv3 --kernel-trace). */
 int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_stream, int steps, double* avg_us);
 
 #ifdef __cplusplus

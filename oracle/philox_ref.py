@@ -1,0 +1,43 @@
+"""
+oracle/philox_ref.py -- NumPy restatement of the Philox4x32-10 counter RNG (Salmon, Moraes, Dror, Shaw: "Parallel
+random numbers: as easy as 1, 2, 3", SC'11; constants of the Random123 reference implementation) and of the
+counter/key convention of the in-kernel episode generator (gym_dockauv_amd/csrc/dockauv_kernels.hip).
+
+TEST INFRASTRUCTURE ONLY.  Pinned by the Random123 known-answer vectors in tests/test_philox.py.
+"""
+import numpy as np
+
+M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+W0, W1 = np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(counter: np.ndarray, key: np.ndarray) -> np.ndarray:
+    """counter [..., 4] uint32, key [..., 2] uint32 -> [..., 4] uint32."""
+    c = np.array(counter, dtype=np.uint64)
+    k = np.broadcast_to(np.array(key, dtype=np.uint64), c.shape[:-1] + (2,)).copy()
+    for _ in range(10):
+        p0 = M0 * c[..., 0]
+        p1 = M1 * c[..., 2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & MASK
+        hi1, lo1 = p1 >> np.uint64(32), p1 & MASK
+        n0 = hi1 ^ c[..., 1] ^ k[..., 0]
+        n2 = hi0 ^ c[..., 3] ^ k[..., 1]
+        c = np.stack([n0, lo1, n2, lo0], axis=-1)
+        k[..., 0] = (k[..., 0] + W0) & MASK
+        k[..., 1] = (k[..., 1] + W1) & MASK
+    return c.astype(np.uint32)
+
+
+def episode_uniforms(seed: int, env: np.ndarray, episode: np.ndarray) -> np.ndarray:
+    """The 12 uniforms the kernel draws for (env, episode): counter = (env, episode, block, 0), key = seed,
+    U = (x >> 8) * 2^-24.  Returns [n, 12] float64."""
+    env = np.asarray(env, dtype=np.uint64)
+    episode = np.asarray(episode, dtype=np.uint64)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    out = []
+    for blk in range(3):
+        ctr = np.stack([env, episode, np.full_like(env, blk), np.zeros_like(env)], axis=-1)
+        x = philox4x32_10(ctr, key)
+        out.append((x >> np.uint32(8)).astype(np.float64) / 16777216.0)
+    return np.concatenate(out, axis=-1)

@@ -1,0 +1,119 @@
+"""GPU: in-kernel episode reset.
+  * DOCKAUV_RESET_DEVICE: the Philox4x32-10 draws are bit-exact integer work -> the generated episodes must equal the
+    host generators (gym_dockauv_amd/scenarios.py, pinned against the reference's reset draws) fed with the NumPy
+    Philox restatement (oracle/philox_ref.py, pinned against the Random123 vectors), to float rounding.
+  * DOCKAUV_RESET_POOL: VecEnv semantics -- state comes from the staged pool, returned obs is the reference's reset
+    observation (zeros, Q8), the terminal observation is delivered separately."""
+import copy
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCN = ["SimpleDocking3d", "SimpleCurrentDocking3d", "CapsuleDocking3d", "CapsuleCurrentDocking3d",
+       "ObstaclesDocking3d", "ObstaclesNoCapDocking3d", "ObstaclesCurrentDocking3d"]
+
+
+def cfg_short(max_t):
+    from gym_dockauv_amd.config.env_config import BASE_CONFIG
+    cfg = copy.deepcopy(BASE_CONFIG)
+    cfg["max_timesteps"] = max_t
+    return cfg
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("scenario", SCN)
+def test_device_reset_matches_philox_reference(scenario, precision):
+    from gym_dockauv_amd import _capi, scenarios
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    from oracle import philox_ref
+    N, seed = 333, 0x1234ABCD5678
+    env = BatchedDocking3d(cfg_short(2), num_envs=N, scenario=scenario, precision=precision, reset_mode="device",
+                           device_seed=seed, rng="batched")
+    try:
+        env.reset()
+        a = np.zeros((N, env.n_u))
+        for t in range(3):
+            obs, rew, done, infos = env.step(a)
+            assert done.all() == (t == 2), f"step {t}: done = {done.sum()}"
+        # all envs hit max_timesteps at the third step and were regenerated in-kernel as episode 2
+        assert np.all(obs == 0)
+        assert "terminal_observation" in infos[0] and np.abs(infos[0]["terminal_observation"]).max() > 0
+        U = philox_ref.episode_uniforms(seed, np.arange(N), np.full(N, 2))
+        ref = scenarios.episodes_from_uniforms(scenario, U, env.config["max_attitude"], env.config["max_dist_from_goal"],
+                                               env.max_capsules, env.max_spheres)
+        tol = 1e-12 if precision == "f64" else 2e-6
+        st = env.state
+        np.testing.assert_allclose(st[:, 0:6], ref["pose"], rtol=0, atol=tol * 15)
+        assert np.all(st[:, 6:] == 0) and np.all(env.u == 0)
+        goal = env.get_field(_capi.F_GOAL)
+        np.testing.assert_allclose(goal[:, 0:3], ref["goal"][:, 0:3], rtol=0, atol=tol * 4)
+        d = np.abs(goal[:, 3] - ref["goal"][:, 3])
+        assert np.minimum(d, 2 * np.pi - d).max() <= tol * 4
+        np.testing.assert_allclose(env.get_field(_capi.F_CURRENT), ref["current"], rtol=0, atol=tol * 4)
+        if env.max_capsules:
+            np.testing.assert_allclose(env.get_field(_capi.F_CAPSULES), ref["capsules"], rtol=0, atol=tol * 20)
+        assert np.all(env.t_steps == 0) and np.all(env.cumulative_reward == 0)
+        assert np.all(env.get_field(_capi.F_EPISODE)[:, 0] == 2)
+        # the regenerated episodes must be steppable
+        obs, rew, done, _ = env.step(a)
+        assert np.isfinite(obs).all() and np.isfinite(rew).all() and not done.any()
+    finally:
+        env.close()
+
+
+def test_pool_autoreset_vecenv_semantics():
+    from gym_dockauv_amd import _capi
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    N = 130
+    env = BatchedDocking3d(cfg_short(1), num_envs=N, scenario="CapsuleCurrentDocking3d", precision="f32",
+                           reset_mode="pool", rng="batched")
+    try:
+        env.reset()
+        pool_pose = env.get_field(_capi.F_POOL_POSE)
+        pool_goal = env.get_field(_capi.F_POOL_GOAL)
+        pool_cur = env.get_field(_capi.F_POOL_CURRENT)
+        a = np.random.RandomState(0).uniform(-1, 1, (N, env.n_u))
+        obs1, _, done1, _ = env.step(a)
+        assert not done1.any() and np.abs(obs1).max() > 0
+        # second step: t_steps (1) >= max_timesteps (1) -> done for all, reset from the pool inside the kernel
+        env.rng_mode = "frozen"     # keep the host from restaging, so the live state must equal the old pool
+        obs2, rew2, done2, infos = env.step(a)
+        assert done2.all() and np.all(obs2 == 0)
+        term = np.stack([i["terminal_observation"] for i in infos])
+        assert np.abs(term).max() > 0 and np.isfinite(term).all()
+        assert all(i["conditions_true"] == [3] for i in infos)
+        st = env.state
+        np.testing.assert_allclose(st[:, 0:6], pool_pose, atol=1e-6)
+        assert np.all(st[:, 6:] == 0) and np.all(env.u == 0) and np.all(env.t_steps == 0)
+        np.testing.assert_allclose(env.get_field(_capi.F_GOAL), pool_goal, atol=1e-6)
+        np.testing.assert_allclose(env.get_field(_capi.F_CURRENT), pool_cur, atol=1e-6)
+        assert np.all(env.cumulative_reward == 0)
+    finally:
+        env.close()
+
+
+def test_tail_group_and_large_batch():
+    """N not a multiple of 64 (partial last workgroup) and a batch large enough to fill the chip several times:
+    envs are independent, so a big batch made of copies of a small one must reproduce the small one exactly."""
+    from gym_dockauv_amd import _capi
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    small = BatchedDocking3d(num_envs=77, scenario="ObstaclesDocking3d", reset_mode="none", rng="batched")
+    big = BatchedDocking3d(num_envs=77 * 400 + 13, scenario="ObstaclesDocking3d", reset_mode="none", rng="batched")
+    try:
+        small.reset()
+        reps = -(-big.num_envs // 77)
+        for f in (_capi.F_STATE, _capi.F_GOAL, _capi.F_CURRENT, _capi.F_CAPSULES):
+            big.set_field(f, np.tile(small.get_field(f), (reps, 1))[: big.num_envs])
+        rs = np.random.RandomState(3)
+        for t in range(5):
+            a = rs.uniform(-1, 1, (77, 6))
+            o_s, r_s, d_s, _ = small.step(a)
+            o_b, r_b, d_b, _ = big.step(np.tile(a, (reps, 1))[: big.num_envs])
+            assert np.array_equal(np.tile(o_s, (reps, 1))[: big.num_envs], o_b)
+            assert np.array_equal(np.tile(r_s, reps)[: big.num_envs], r_b)
+            assert np.array_equal(np.tile(d_s, reps)[: big.num_envs], d_b)
+    finally:
+        small.close()
+        big.close()
