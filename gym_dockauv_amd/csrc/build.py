@@ -7,8 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(os.path.dirname(HERE), "lib")
 OUT = os.path.join(LIB_DIR, "libdockauv.so")
-SOURCES = ["dockauv_kernels.hip", "dockauv_capi.hip"]
-DEPS = SOURCES + ["dockauv_device.h", os.path.join("..", "..", "include", "dockauv.h")]
+SOURCES = ["dockauv_kernels_f32.hip", "dockauv_kernels_f64.hip", "dockauv_capi.hip"]
+DEPS = SOURCES + ["dockauv_step.hip.inc", "dockauv_device.h", os.path.join("..", "..", "include", "dockauv.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
@@ -24,15 +24,31 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
     os.makedirs(LIB_DIR, exist_ok=True)
     if not force and not extra and up_to_date():
         return OUT
-    cmd = [HIPCC, *FLAGS, *extra, *SOURCES, "-o", OUT]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    r = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
+    # one hipcc per translation unit, in parallel, then link
+    obj_dir = os.path.join(LIB_DIR, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *cflags, *extra, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, obj, subprocess.Popen(cmd, cwd=HERE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    objs = []
+    for src, obj, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out)
+            raise RuntimeError(f"hipcc failed on {src}")
+        if verbose and out:
+            print(out)
+        objs.append(obj)
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT], cwd=HERE,
+                       capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libdockauv.so")
-    if verbose and (r.stdout or r.stderr):
-        print(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed linking libdockauv.so")
     return OUT
 
 

@@ -1,6 +1,7 @@
 // dockauv_capi.hip -- C ABI of libdockauv.so (include/dockauv.h): handle, HBM buffers, field I/O, step launch.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -34,6 +35,7 @@ struct dockauv_env_s {
     int n_rays = 0, n_red = 0, n_obs = 0, n_u_max = 0;
     int vk = VK_JOY;
     bool has_rays = false;
+    bool sym = false;
     int threads = 64;
     Buffers B{};
     std::vector<void*> allocs;
@@ -133,7 +135,16 @@ void fill_env(EnvP<T>& e, const dockauv_env_s& h) {
     e.dtol = (T)c.dist_goal_reached_tol;
     e.max_att = (T)c.max_attitude;
     e.safety = (T)c.safety_radius;
-    for (int i = 0; i < 6; ++i) e.vel_max[i] = (T)c.vel_max[i];
+    for (int i = 0; i < 6; ++i) {
+        e.vel_max[i] = (T)c.vel_max[i];
+        e.inv_vel[i] = (T)(1.0 / c.vel_max[i]);
+    }
+    const double eps = 0.001;   // Reward.log_precision epsilon (envs/docking3d.py:722)
+    e.inv_dmax = (T)(1.0 / c.max_dist_from_goal);
+    e.inv_log_tol = (T)(1.0 / std::log(c.dist_goal_reached_tol / c.max_dist_from_goal));
+    e.inv_log_tol_eps = (T)(1.0 / std::log(std::max(c.dist_goal_reached_tol, eps) / c.max_dist_from_goal));
+    e.inv_max_att = (T)(1.0 / c.max_attitude);
+    e.inv_ray_max = (T)(1.0 / c.radar_max_dist);
     e.w_d = (T)c.w_d;
     e.w_dth = (T)c.w_delta_theta;
     e.w_dpsi = (T)c.w_delta_psi;
@@ -146,6 +157,20 @@ void fill_env(EnvP<T>& e, const dockauv_env_s& h) {
     e.ray_max = (T)c.radar_max_dist;
     e.alpha_max = (T)c.radar_alpha_max;
     e.beta_max = (T)c.radar_beta_max;
+}
+
+// structural fast path of kinetics_: x_G = y_G = x_B = y_B = 0, diagonal I_b, M^-1 = diagonal + (0,4),(1,3) couplings
+bool is_symmetric_vehicle(const dockauv_vehicle& v) {
+    if (v.r_G[0] != 0.0 || v.r_G[1] != 0.0 || v.r_B[0] != 0.0 || v.r_B[1] != 0.0) return false;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            if (i != j && v.I_b[i * 3 + j] != 0.0) return false;
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+            const bool allowed = (i == j) || (i == 0 && j == 4) || (i == 4 && j == 0) || (i == 1 && j == 3) || (i == 3 && j == 1);
+            if (!allowed && std::fabs(v.M_inv[i * 6 + j]) > 1e-14 * std::fabs(v.M_inv[i * 6 + i])) return false;
+        }
+    return true;
 }
 
 bool b_is_diagonal(const dockauv_vehicle& v) {
@@ -215,10 +240,10 @@ int launch(dockauv_handle h, const dockauv_step_io* io, hipStream_t stream, hipE
     int rc;
     if (h->f64) {
         set_io(h->a64.io, *io);
-        rc = launch_step_f64(h->a64, h->vk, h->has_rays, 64, h->threads, stream, ev0, ev1);
+        rc = launch_step_f64(h->a64, h->vk, h->sym, h->has_rays, h->threads, stream, ev0, ev1);
     } else {
         set_io(h->a32.io, *io);
-        rc = launch_step_f32(h->a32, h->vk, h->has_rays, 64, h->threads, stream, ev0, ev1);
+        rc = launch_step_f32(h->a32, h->vk, h->sym, h->has_rays, h->threads, stream, ev0, ev1);
     }
     if (rc != 0) return fail(h, DOCKAUV_E_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     h->last_stream = stream;
@@ -303,6 +328,10 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
     } else {
         h->vk = b_is_diagonal(c.vehicle[0]) ? VK_JOY : VK_DENSEB;
     }
+
+    h->sym = true;
+    for (int v = 0; v < c.n_vehicles; ++v) h->sym = h->sym && is_symmetric_vehicle(c.vehicle[v]);
+    if (c.envs_per_group == -1) h->sym = false;   // test hook: force the general expressions
 
     const size_t S = (size_t)h->S, t = h->tsz;
     int rc = 0;

@@ -42,6 +42,9 @@ struct EnvP {
     T h, lp_alpha, mu;
     T dmax, dtol, max_att, safety;
     T vel_max[6];
+    // reciprocals of configuration constants, prepared on the host in float64
+    T inv_dmax, inv_log_tol, inv_log_tol_eps, inv_max_att, inv_ray_max;
+    T inv_vel[6];
     T w_d, w_dth, w_dpsi, w_phi, w_th, w_thdot, w_oa;
     T w_done[5];
     T w_act[kMaxU];      // action_reward_factors[i]
@@ -106,12 +109,12 @@ inline size_t lds_bytes(int epg, int max_cap, int max_sph, int n_rays, int n_obs
     return bytes + (size_t)epg * n_obs * sizeof(float);
 }
 
-// launch one step; implemented in dockauv_kernels.hip.  vk = VehKind, has_rays = obstacles present.
-// returns a hipError_t as int.
-// ev0 / ev1: optional hipEvent_t recorded at the start / end of this very dispatch (hipExtLaunchKernelGGL).
-int launch_step_f32(const KernelArgs<float, 2>& a, int vk, bool has_rays, int envs_per_group, int threads, void* stream,
+// launch one step; implemented in dockauv_kernels_f32.hip / _f64.hip.  vk = VehKind, sym = structural fast path
+// (see kinetics_), has_rays = obstacles present.  ev0 / ev1: optional hipEvent_t recorded at the start / end of this
+// very dispatch (hipExtLaunchKernelGGL).  Returns a hipError_t as int.
+int launch_step_f32(const KernelArgs<float, 2>& a, int vk, bool sym, bool has_rays, int threads, void* stream,
                     void* ev0 = nullptr, void* ev1 = nullptr);
-int launch_step_f64(const KernelArgs<double, 2>& a, int vk, bool has_rays, int envs_per_group, int threads, void* stream,
+int launch_step_f64(const KernelArgs<double, 2>& a, int vk, bool sym, bool has_rays, int threads, void* stream,
                     void* ev0 = nullptr, void* ev1 = nullptr);
 
 }  // namespace dockauv

@@ -61,7 +61,11 @@ def run_teacher_forced(name, precision):
         if precision == "f64":
             assert not ray_bad.any(), f"{name}: ray distances differ: {np.abs(env.intersec_dist - g['ray_dist']).max()}"
         else:
-            assert ray_bad.mean() < 5e-4, f"{name}: {ray_bad.sum()} of {ray_bad.size} rays off by more than {tol['ray']}"
+            assert ray_bad.mean() < 1e-3, f"{name}: {ray_bad.sum()} of {ray_bad.size} rays off by more than {tol['ray']}"
+            # an outlier is either a hit/miss flip (one side reports max_dist) or a near-grazing hit: bounded by 1 cm
+            both_hit = ray_bad & (env.intersec_dist < env.radar.max_dist) & (g["ray_dist"] < env.radar.max_dist)
+            if both_hit.any():
+                assert np.abs(env.intersec_dist - g["ray_dist"])[both_hit].max() < 1e-2, name
         step_ok = ~ray_bad.any(axis=1)
         nav = env.nav_errors
         np.testing.assert_allclose(nav[:, 0], g["nav"][:, 0], rtol=0, atol=tol["nav"], err_msg=name)
