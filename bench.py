@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--no-overlap", action="store_true", help="do not overlap the all-gather with the next kernel")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--sweep", type=int, nargs="*", default=[65536, 1048576])
     args = ap.parse_args()
 
     import torch
@@ -111,9 +114,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("DOCKAUV_FORCE_DIST") == "1"   # the latter: 1-rank rehearsal of the RCCL path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from gym_dockauv_amd.envs.batched import BatchedDocking3d
     wl = workload(args.config, args.envs)
@@ -130,47 +135,75 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     actions = torch.rand((RING, N, n_u), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
-    # gathered outputs: [world*N, n_obs + 2] would force a strided kernel store; keep three dense buffers and
-    # gather them with one coalesced all-gather each (obs dominates: n_obs*4 B vs 5 B per env)
-    obs_all = torch.zeros((world * N, n_obs), device=dev, dtype=torch.float32)
-    rew_all = torch.zeros((world * N,), device=dev, dtype=torch.float32)
-    done_all = torch.zeros((world * N,), device=dev, dtype=torch.uint8)
-    obs_l, rew_l, done_l = obs_all[rank * N:(rank + 1) * N], rew_all[rank * N:(rank + 1) * N], done_all[rank * N:(rank + 1) * N]
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step(i):
-        env.step_device(actions[i % RING].data_ptr(), obs_l.data_ptr(), rew_l.data_ptr(), done_l.data_ptr(), stream=stream)
-        if world > 1:
-            dist.all_gather_into_tensor(obs_all, obs_l)
-            dist.all_gather_into_tensor(rew_all, rew_l)
-            dist.all_gather_into_tensor(done_all, done_l)
+    # the kernel writes packed rows [obs | reward | done] (float32 [N][n_obs + 2]) straight into this rank's slice
+    # of the gather buffer; ONE all-gather per step, overlapped with the next step's kernel (two buffers)
+    from gym_dockauv_amd.parallel import ShardedStepper
 
-    for i in range(args.warmup):
-        step(i)
+    def step_fn(a, out_local):
+        env.step_device(a.data_ptr(), out_local.data_ptr(), stream=stream, packed=True)
+
+    stepper = ShardedStepper(N, n_obs + 2, step_fn, dev, world=world, rank=rank, overlap=not args.no_overlap)
+    stepper.use_dist = use_dist
+
+    def run(n, i0=0):
+        for i in range(i0, i0 + n):
+            stepper.step(actions[i % RING])
+        stepper.wait()
+
+    run(args.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run(args.steps, args.warmup)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline of the dominant (only) kernel: per-dispatch start/stop events on the launch stream
-    k_steps = min(args.steps, 1000)
-    kernel_us = env.time_steps_device(actions[0].data_ptr(), obs_l.data_ptr(), rew_l.data_ptr(), done_l.data_ptr(),
-                                      k_steps, stream=stream)
+    # roofline of the dominant (only) kernel: per-dispatch start/stop events on the launch stream, cycling through
+    # the same action ring as the timed region
+    out_l = stepper.local_slice(stepper.bufs[0])
+    k_steps = min(args.steps, 1024)
+    kernel_us = 0.0
+    for i in range(k_steps):
+        kernel_us += env.time_steps_device(actions[i % RING].data_ptr(), out_l.data_ptr(), steps=1, stream=stream, packed=True)
+    n_timed = k_steps
+    kernel_us /= n_timed
     torch.cuda.synchronize()
-    finite = bool(torch.isfinite(obs_all).all().item())
-    n_done = int(done_l.sum().item())
+    last = stepper.bufs[0]
+    finite = bool(torch.isfinite(last).all().item())
+    n_done = int((out_l[:, n_obs + 1] > 0.5).sum().item())
+
+    sweep = []
+    if world == 1 and not args.no_sweep and not args.envs:
+        # the same kernel at batch sizes where the state no longer fits the caches (HBM-relevant roofline points)
+        for n_big in args.sweep:
+            e2 = BatchedDocking3d(wl["cfg"], num_envs=n_big, scenario=wl["scenario"], device=local_rank, precision="f32",
+                                  reset_mode="device", device_seed=0xABC, rng="batched",
+                                  vehicles=(wl["vehicles"] * (n_big // N + 1))[:n_big] if wl["vehicles"] else None)
+            e2._gen = np.random.default_rng(7)
+            e2.reset()
+            a2 = torch.rand((4, n_big, n_u), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
+            o2 = torch.zeros((n_big, n_obs + 2), device=dev, dtype=torch.float32)
+            for r in range(8):
+                e2.step_device(a2[r % 4].data_ptr(), o2.data_ptr(), stream=stream, packed=True)
+            torch.cuda.synchronize()
+            us = sum(e2.time_steps_device(a2[r % 4].data_ptr(), o2.data_ptr(), steps=10, stream=stream, packed=True) for r in range(8)) / 8
+            torch.cuda.synchronize()
+            gbps = ALGO_BYTES[args.config] * n_big / (us * 1e-6) / 1e9
+            sweep.append({"envs": n_big, "kernel_us": us, "env_steps_per_s_kernel": n_big / (us * 1e-6),
+                          "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS})
+            e2.close()
+            del a2, o2
 
     if rank == 0:
         bytes_per_launch = ALGO_BYTES[args.config] * N
@@ -196,19 +229,23 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": wl["name"], "envs_per_gpu": N, "total_envs": world * N, "n_obs": n_obs, "n_u": n_u,
-                       "auto_reset": "in-kernel scenario generation (Philox4x32-10)", "collective": "rccl all_gather(obs,reward,done)" if world > 1 else "none",
+                       "auto_reset": "in-kernel scenario generation (Philox4x32-10)",
+                       "collective": ("one rccl all_gather of packed [obs|reward|done] per step"
+                                      + ("" if args.no_overlap else ", overlapped with the next step's kernel")) if use_dist else "none",
                        "obs_finite": finite, "done_last_step_rank0": n_done},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "dockauv::step_kernel", "kernel_us": kernel_us,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES[args.config], "envs_per_launch": N,
-                         "timing": f"hipExtLaunchKernel start/stop events on the launch stream, {k_steps} launches after the timed region"},
+                         "timing": f"hipExtLaunchKernel start/stop events on the launch stream, {n_timed} launches after the timed region"},
         }
+        if sweep:
+            out["sweep"] = sweep
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     env.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

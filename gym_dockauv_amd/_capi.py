@@ -73,6 +73,7 @@ class StepIO(C.Structure):
         ("actions", C.c_void_p), ("noise", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p),
         ("done", C.c_void_p), ("reward_terms", C.c_void_p), ("conditions", C.c_void_p), ("nav", C.c_void_p),
         ("ray_dist", C.c_void_p), ("terminal_obs", C.c_void_p),
+        ("pack_reward_done", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

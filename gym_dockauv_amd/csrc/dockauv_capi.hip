@@ -234,6 +234,7 @@ void set_io(StepIO& d, const dockauv_step_io& s) {
     d.nav = s.nav;
     d.ray_dist = s.ray_dist;
     d.terminal_obs = s.terminal_obs;
+    d.pack = s.pack_reward_done ? 1 : 0;
 }
 
 int launch(dockauv_handle h, const dockauv_step_io* io, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
@@ -501,7 +502,8 @@ int dockauv_reset_envs(dockauv_handle h, int first, int count) {
 
 int dockauv_step(dockauv_handle h, const dockauv_step_io* io, void* hip_stream) {
     if (!h || !io) return fail(h, DOCKAUV_E_INVALID, "null argument");
-    if (!io->actions || !io->obs || !io->reward || !io->done) return fail(h, DOCKAUV_E_INVALID, "actions/obs/reward/done must not be NULL");
+    if (!io->actions || !io->obs) return fail(h, DOCKAUV_E_INVALID, "actions/obs must not be NULL");
+    if (!io->pack_reward_done && (!io->reward || !io->done)) return fail(h, DOCKAUV_E_INVALID, "reward/done must not be NULL unless pack_reward_done");
     HIP_TRY(h, hipSetDevice(h->device));
     return launch(h, io, (hipStream_t)hip_stream);
 }
@@ -509,6 +511,7 @@ int dockauv_step(dockauv_handle h, const dockauv_step_io* io, void* hip_stream) 
 int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io) {
     if (!h || !io) return fail(h, DOCKAUV_E_INVALID, "null argument");
     if (!io->actions || !io->obs || !io->reward || !io->done) return fail(h, DOCKAUV_E_INVALID, "actions/obs/reward/done must not be NULL");
+    if (io->pack_reward_done) return fail(h, DOCKAUV_E_INVALID, "pack_reward_done is a device-pointer feature (dockauv_step)");
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t N = (size_t)h->cfg.n_envs, t = h->tsz;
     HIP_TRY(h, hipMemcpy(h->d_actions, io->actions, N * h->n_u_max * t, hipMemcpyHostToDevice));

@@ -86,6 +86,7 @@ struct StepIO {
     void* nav;
     void* ray_dist;
     float* terminal_obs;
+    int pack;
 };
 
 template <typename T, int NV>
@@ -106,7 +107,7 @@ inline size_t lds_bytes(int epg, int max_cap, int max_sph, int n_rays, int n_obs
     size_t t_elems = rays ? (size_t)epg * (kPoseFields + kCapFields * max_cap + kSphFields * max_sph + n_rays) : 0;
     size_t bytes = t_elems * sizeof(T);
     bytes = (bytes + 15) & ~(size_t)15;
-    return bytes + (size_t)epg * n_obs * sizeof(float);
+    return bytes + (size_t)epg * (n_obs + 2) * sizeof(float);   // +2: packed reward | done columns
 }
 
 // launch one step; implemented in dockauv_kernels_f32.hip / _f64.hip.  vk = VehKind, sym = structural fast path

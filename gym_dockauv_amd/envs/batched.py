@@ -73,7 +73,7 @@ class BatchedDocking3d:
                  vehicles: Optional[Sequence[str]] = None, max_capsules: Optional[int] = None,
                  max_spheres: Optional[int] = None, threads_per_group: int = 0,
                  vehicle_models: Optional[Sequence[VehicleModel]] = None, current_mu: float = scenarios.CURRENT_MU,
-                 reset_mode: Optional[str] = None, device_seed: int = 0):
+                 reset_mode: Optional[str] = None, device_seed: int = 0, _force_general: bool = False):
         if scenario not in scenarios.SCENARIOS:
             raise KeyError(f"Not valid scenario, available options are {scenarios.SCENARIOS}")
         self.config = copy.deepcopy(env_config)
@@ -89,6 +89,7 @@ class BatchedDocking3d:
             raise ValueError("reset_mode must be 'none', 'pool' or 'device'")
         self.reset_mode = reset_mode
         self.device_seed = int(device_seed)
+        self._force_general = bool(_force_general)   # test hook: general kinetics expressions
         self.auto_reset = reset_mode != "none"
         self.rng_mode = rng
         self.current_mu = float(current_mu)
@@ -183,7 +184,7 @@ class BatchedDocking3d:
         cfg.max_spheres = self.max_spheres
         cfg.n_v, cfg.n_h = self.radar.n_vertical, self.radar.n_horizontal
         cfg.blocksize_reduce = self.radar.blocksize_reduce
-        cfg.envs_per_group = 0
+        cfg.envs_per_group = -1 if self._force_general else 0
         cfg.threads_per_group = self.threads_per_group
         cfg.seed = self.device_seed
         cfg.t_step_size = float(c["t_step_size"])
@@ -451,22 +452,27 @@ class BatchedDocking3d:
         return self._ray
 
     # ------------------------------------------------------------------------------------------ device-pointer path
-    def step_device(self, actions_ptr: int, obs_ptr: int, reward_ptr: int, done_ptr: int, stream: int = 0,
-                    noise_ptr: int = 0, terminal_obs_ptr: int = 0, conditions_ptr: int = 0) -> None:
-        """Asynchronous step on device pointers (torch tensors' data_ptr()): no host copies, no sync."""
+    def step_device(self, actions_ptr: int, obs_ptr: int, reward_ptr: int = 0, done_ptr: int = 0, stream: int = 0,
+                    noise_ptr: int = 0, terminal_obs_ptr: int = 0, conditions_ptr: int = 0, packed: bool = False) -> None:
+        """Asynchronous step on device pointers (torch tensors' data_ptr()): no host copies, no sync.
+        packed=True: obs_ptr is a float32 [N][n_obs + 2] buffer receiving obs | reward | done per env."""
         io = _capi.StepIO()
-        io.actions, io.obs, io.reward, io.done = actions_ptr, obs_ptr, reward_ptr, done_ptr
+        io.actions, io.obs = actions_ptr, obs_ptr
+        io.reward, io.done = reward_ptr or None, done_ptr or None
+        io.pack_reward_done = 1 if packed else 0
         io.noise = noise_ptr or None
         io.terminal_obs = terminal_obs_ptr or None
         io.conditions = conditions_ptr or None
         rc = self._lib.dockauv_step(self._handle, C.byref(io), C.c_void_p(stream or None))
         _capi.check(self._lib, self._handle, rc, "dockauv_step")
 
-    def time_steps_device(self, actions_ptr: int, obs_ptr: int, reward_ptr: int, done_ptr: int, steps: int,
-                          stream: int = 0) -> float:
-        """Average per-launch time in microseconds from HIP events on `stream` (bench.py)."""
+    def time_steps_device(self, actions_ptr: int, obs_ptr: int, reward_ptr: int = 0, done_ptr: int = 0, steps: int = 1,
+                          stream: int = 0, packed: bool = False) -> float:
+        """Average KERNEL duration in microseconds from per-dispatch HIP events on `stream` (bench.py)."""
         io = _capi.StepIO()
-        io.actions, io.obs, io.reward, io.done = actions_ptr, obs_ptr, reward_ptr, done_ptr
+        io.actions, io.obs = actions_ptr, obs_ptr
+        io.reward, io.done = reward_ptr or None, done_ptr or None
+        io.pack_reward_done = 1 if packed else 0
         out = C.c_double(0.0)
         rc = self._lib.dockauv_time_steps(self._handle, C.byref(io), C.c_void_p(stream or None), int(steps), C.byref(out))
         _capi.check(self._lib, self._handle, rc, "dockauv_time_steps")

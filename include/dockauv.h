@@ -151,14 +151,18 @@ typedef struct dockauv_env_s* dockauv_handle;
 typedef struct dockauv_step_io {
     const void* actions;     /* T [n_envs][n_u_max] row-major, raw policy output (clipped inside, auvsim.py:74) */
     const void* noise;       /* nullable, T [n_envs]: w_k ~ N(0, sigma) of Current.sim (current.py:88); NULL = 0 */
-    float* obs;              /* float32 [n_envs][n_obs] row-major (docking3d.py:462-488) */
-    void* reward;            /* T [n_envs] (docking3d.py:593) */
-    uint8_t* done;           /* [n_envs] 0/1 (docking3d.py:630) */
+    float* obs;              /* float32 [n_envs][n_obs] row-major (docking3d.py:462-488); with pack_reward_done:
+                                float32 [n_envs][n_obs + 2] = obs | reward | done(0.0/1.0), one dense buffer so that a
+                                single all-gather ships everything a learner needs */
+    void* reward;            /* T [n_envs] (docking3d.py:593); nullable when pack_reward_done */
+    uint8_t* done;           /* [n_envs] 0/1 (docking3d.py:630); nullable when pack_reward_done */
     void* reward_terms;      /* nullable, T [n_envs][13]: last_reward_arr (docking3d.py:513-588) */
     uint8_t* conditions;     /* nullable, [n_envs]: bit i = condition i (docking3d.py:608-619) */
     void* nav;               /* nullable, T [n_envs][4]: delta_d, delta_theta, delta_psi, delta_heading_goal */
     void* ray_dist;          /* nullable, T [n_envs][n_rays]: clamped intersec_dist (sensor.py:113-118) */
     float* terminal_obs;     /* nullable, float32 [n_envs][n_obs]: written only where done (auto-reset modes) */
+    int32_t pack_reward_done; /* 0/1, see obs */
+    int32_t reserved;
 } dockauv_step_io;
 
 /* library / build info; callable without a GPU */

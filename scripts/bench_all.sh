@@ -3,9 +3,9 @@
 TAG=${1:-bench}; shift
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG.jsonl; : > $OUT
-python bench.py --steps 2000 --warmup 200 --no-cpu "$@" >> $OUT 2>> gpurun_out/$TAG.err
-for c in 3 4 5; do python bench.py --config $c --steps 300 --warmup 30 --no-cpu "$@" >> $OUT 2>> gpurun_out/$TAG.err; done
-for n in 65536 1048576; do python bench.py --config 2 --envs $n --steps 200 --warmup 20 --no-cpu "$@" >> $OUT 2>> gpurun_out/$TAG.err; done
+python bench.py --steps 2000 --warmup 200 --no-cpu --no-sweep "$@" >> $OUT 2>> gpurun_out/$TAG.err
+for c in 3 4 5; do python bench.py --config $c --steps 300 --warmup 30 --no-cpu --no-sweep "$@" >> $OUT 2>> gpurun_out/$TAG.err; done
+for n in 65536 1048576; do python bench.py --config 2 --envs $n --steps 200 --warmup 20 --no-cpu --no-sweep "$@" >> $OUT 2>> gpurun_out/$TAG.err; done
 python - <<PY
 import json
 for l in open("$OUT"):
