@@ -6,7 +6,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(os.path.dirname(HERE), "lib")
-OUT = os.path.join(LIB_DIR, "libdockauv.so")
+OUT = os.path.join(LIB_DIR, os.environ.get("DOCKAUV_LIB_NAME", "libdockauv.so"))
 SOURCES = ["dockauv_kernels_f32.hip", "dockauv_kernels_f64.hip", "dockauv_capi.hip"]
 DEPS = SOURCES + ["dockauv_step.hip.inc", "dockauv_device.h", os.path.join("..", "..", "include", "dockauv.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -25,7 +25,7 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
     if not force and not extra and up_to_date():
         return OUT
     # one hipcc per translation unit, in parallel, then link
-    obj_dir = os.path.join(LIB_DIR, "obj")
+    obj_dir = os.path.join(LIB_DIR, "obj" + os.environ.get("DOCKAUV_OBJ_TAG", ""))
     os.makedirs(obj_dir, exist_ok=True)
     cflags = [f for f in FLAGS if f != "-shared"]
     procs = []
