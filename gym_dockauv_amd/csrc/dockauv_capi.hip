@@ -396,8 +396,8 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
         h->a32.B = B;
     }
     // the dynamic-LDS request must fit the 160 KiB of a gfx950 CU
-    size_t lds = h->f64 ? lds_bytes<double>(64, c.max_capsules, c.max_spheres, h->n_rays, h->n_obs, h->has_rays)
-                        : lds_bytes<float>(64, c.max_capsules, c.max_spheres, h->n_rays, h->n_obs, h->has_rays);
+    size_t lds = h->f64 ? lds_bytes<double>(64, 256, c.max_capsules, c.max_spheres, h->n_obs, h->has_rays)
+                        : lds_bytes<float>(64, 256, c.max_capsules, c.max_spheres, h->n_obs, h->has_rays);
     if (lds > 160 * 1024) {
         fail(nullptr, DOCKAUV_E_INVALID, "configuration needs %zu B of LDS per group (> 160 KiB): fewer rays/obstacles", lds);
         dockauv_destroy(h);

@@ -103,8 +103,8 @@ constexpr int kSphFields = 4;    // oc(3), r^2
 constexpr int kPoseFields = 14;  // pos(3) R(9) n_cap n_sph
 
 template <typename T>
-inline size_t lds_bytes(int epg, int max_cap, int max_sph, int n_rays, int n_obs, bool rays) {
-    size_t t_elems = rays ? (size_t)epg * (kPoseFields + kCapFields * max_cap + kSphFields * max_sph + n_rays) : 0;
+inline size_t lds_bytes(int epg, int nt, int max_cap, int max_sph, int n_obs, bool rays) {
+    size_t t_elems = rays ? (size_t)epg * (kPoseFields + kCapFields * max_cap + kSphFields * max_sph + 2 * (nt / epg)) : 0;
     size_t bytes = t_elems * sizeof(T);
     bytes = (bytes + 15) & ~(size_t)15;
     return bytes + (size_t)epg * (n_obs + 2) * sizeof(float);   // +2: packed reward | done columns
