@@ -387,13 +387,31 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
 #undef ALLOC
 
     if (h->f64) {
-        fill_env(h->a64.E, *h);
-        for (int v = 0; v < c.n_vehicles; ++v) fill_vehicle(h->a64.V[v], c.vehicle[v]);
+        fill_env(h->a64.P.E, *h);
+        for (int v = 0; v < c.n_vehicles; ++v) fill_vehicle(h->a64.P.V[v], c.vehicle[v]);
         h->a64.B = B;
     } else {
-        fill_env(h->a32.E, *h);
-        for (int v = 0; v < c.n_vehicles; ++v) fill_vehicle(h->a32.V[v], c.vehicle[v]);
+        fill_env(h->a32.P.E, *h);
+        for (int v = 0; v < c.n_vehicles; ++v) fill_vehicle(h->a32.P.V[v], c.vehicle[v]);
         h->a32.B = B;
+    }
+    {
+        // the parameter block is read by the kernel from device memory (dockauv_device.h: ParamBlock)
+        const void* src = h->f64 ? (const void*)&h->a64.P : (const void*)&h->a32.P;
+        const size_t bytes = h->f64 ? sizeof(h->a64.P) : sizeof(h->a32.P);
+        void* pdev = nullptr;
+        if ((rc = dalloc(h, &pdev, bytes)) != 0) {
+            g_create_error = h->err;
+            dockauv_destroy(h);
+            return rc;
+        }
+        e = hipMemcpy(pdev, src, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            fail(nullptr, DOCKAUV_E_HIP, "parameter block upload: %s", hipGetErrorString(e));
+            dockauv_destroy(h);
+            return DOCKAUV_E_HIP;
+        }
+        h->a32.params_dev = h->a64.params_dev = pdev;
     }
     // the dynamic-LDS request must fit the 160 KiB of a gfx950 CU
     size_t lds = h->f64 ? lds_bytes<double>(64, 256, c.max_capsules, c.max_spheres, h->n_obs, h->has_rays)
@@ -572,5 +590,13 @@ int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_st
     *avg_us = total_ms * 1000.0 / steps;
     return 0;
 }
+
+#ifdef DOCKAUV_STAMPS
+// diagnostic build only (scripts/stamps.py): 64 groups x 16 s_memtime stamps of the last f32 step
+int dockauv_debug_read_stamps(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    return dockauv::read_stamps(out);
+}
+#endif
 
 }  // extern "C"

@@ -89,10 +89,29 @@ struct StepIO {
     int pack;
 };
 
+// Vehicle / reward / fan parameters (~1.7 KB in f32).  They live in a DEVICE buffer that persists across launches
+// (uploaded once by dockauv_create) and are read through a constant-address-space pointer: wave-uniform scalar loads
+// (s_load -> SGPR operands) that hit in L2 from the second launch on.  Passing them by value in the kernarg segment
+// made every launch re-fetch 27 fresh cache lines from memory, one exposed miss per first touch (measured: a lone
+// wave spent ~45 % of its life in s_waitcnt).
 template <typename T, int NV>
-struct KernelArgs {
+struct ParamBlock {
     EnvP<T> E;
     VehicleP<T> V[NV];
+};
+
+// host-side bundle of everything a launch needs
+template <typename T, int NV>
+struct KernelArgs {
+    ParamBlock<T, NV> P;      // host copy (grid / LDS sizing, and the source of the device copy)
+    const void* params_dev;   // device copy of P
+    Buffers B;
+    StepIO io;
+};
+
+// what actually travels in the kernarg segment (29 pointers + 2 ints)
+struct DevArgs {
+    const void* params;
     Buffers B;
     StepIO io;
 };
@@ -117,5 +136,9 @@ int launch_step_f32(const KernelArgs<float, 2>& a, int vk, bool sym, bool has_ra
                     void* ev0 = nullptr, void* ev1 = nullptr);
 int launch_step_f64(const KernelArgs<double, 2>& a, int vk, bool sym, bool has_rays, int threads, void* stream,
                     void* ev0 = nullptr, void* ev1 = nullptr);
+
+#ifdef DOCKAUV_STAMPS
+int read_stamps(unsigned long long* out);   // diagnostic build only
+#endif
 
 }  // namespace dockauv

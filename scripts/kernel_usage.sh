@@ -1,7 +1,7 @@
 #!/bin/bash
 # print VGPR / scratch / occupancy / instruction counts of the f32 step kernels
 cd "$(dirname "$0")/../gym_dockauv_amd/csrc"
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -S --cuda-device-only dockauv_kernels_f32.hip -o /tmp/k32.s -Rpass-analysis=kernel-resource-usage 2> /tmp/k32.usage
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-slp-vectorize -S --cuda-device-only dockauv_kernels_f32.hip -o /tmp/k32.s -Rpass-analysis=kernel-resource-usage 2> /tmp/k32.usage
 python3 - <<'PY'
 import re
 from collections import Counter
