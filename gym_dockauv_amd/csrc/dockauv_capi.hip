@@ -105,6 +105,16 @@ void fill_vehicle(VehicleP<T>& d, const dockauv_vehicle& v) {
         d.uhalf[i] = (T)(v.u_hi[i] - v.u_lo[i]);
     }
     for (int i = 0; i < L_COUNT; ++i) d.lauv[i] = (T)v.lauv[i];
+    {
+        const double m = v.m, zg = v.r_G[2];
+        const double* a = v.ma_diag;
+        const double Ix = v.I_b[0], Iy = v.I_b[4], Iz = v.I_b[8];
+        const double kc[10] = {m + a[0], m + a[1], m + a[2], m * zg,
+                               Iy - Iz + a[4] - a[5], a[1] - a[2],
+                               Iz - Ix + a[5] - a[3], a[2] - a[0],
+                               Ix - Iy + a[3] - a[4], a[0] - a[1]};
+        for (int i = 0; i < 10; ++i) d.kc[i] = (T)kc[i];
+    }
     d.n_u = v.n_u;
 }
 

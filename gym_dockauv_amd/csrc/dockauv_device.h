@@ -30,6 +30,10 @@ struct VehicleP {
     T B[6 * kMaxU];      // VK_DENSEB: dense row-major; VK_JOY: only the diagonal B[i*kMaxU+i] is read
     T ulo[kMaxU], uhalf[kMaxU];  // u = ulo + (uhi-ulo) * (clip(a)+1)/2 ; uhalf = (uhi-ulo)
     T lauv[L_COUNT];
+    // structural fast path (kinetics_, SYM): coefficients of the Coriolis + added-mass polynomial, combined on the
+    // host in float64.  kc = { m+ma0, m+ma1, m+ma2, m*z_G,
+    //                          Iy-Iz+ma4-ma5, ma1-ma2,  Iz-Ix+ma5-ma3, ma2-ma0,  Ix-Iy+ma3-ma4, ma0-ma1 }
+    T kc[10];
     int n_u;
 };
 
