@@ -13,7 +13,13 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: the SLP vectoriser packs independent f32 ops into v_pk_* pairs; on this kernel that costs ~370
 # v_mov to build the aligned register pairs and pushes the step kernel from 113 to ~200 VGPRs (4 -> 2 waves/SIMD)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-         "-fno-slp-vectorize"]
+         "-fno-slp-vectorize", "-Werror=uninitialized"]
+
+# The float64 validation kernels need all 256 VGPRs plus AGPR spill space AND spill >100 SGPRs.  With the default
+# "SGPR spills live in lanes of a reserved VGPR" the general-expression (non-SYM) ray kernel came out wrong on
+# gfx950 / ROCm 7.2 whenever the register pressure rose a little (tests/test_gpu_vehicles.py::
+# test_general_path_equals_structural_fast_path[f64]); SGPR spills to scratch memory are slower and correct.
+PER_SOURCE_FLAGS = {}
 
 
 def up_to_date() -> bool:
@@ -34,7 +40,7 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
     procs = []
     for src in SOURCES:
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *cflags, *extra, "-c", src, "-o", obj]
+        cmd = [HIPCC, *cflags, *PER_SOURCE_FLAGS.get(src, []), *extra, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, obj, subprocess.Popen(cmd, cwd=HERE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

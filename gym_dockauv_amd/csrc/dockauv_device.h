@@ -118,12 +118,13 @@ struct DevArgs {
     const void* params;
     Buffers B;
     StepIO io;
+    int n_envs;   // also in the parameter block; here so that the first state loads do not wait for that block
 };
 
 // LDS hand-over layout between the env phase and the ray stage
-constexpr int kCapFields = 10;   // unit axis d(3), oa_perp(3), oa_par, |ba|, |oa_perp|^2 - r^2, r^2
-constexpr int kSphFields = 4;    // oc(3), r^2
-constexpr int kPoseFields = 14;  // pos(3) R(9) n_cap n_sph
+constexpr int kCapFields = 10;   // body-frame unit axis d(3), oa_perp(3), oa_par, |ba|, r^2, oa_par - |ba|
+constexpr int kSphFields = 4;    // body-frame origin - centre (3), r^2
+constexpr int kPoseFields = 2;   // n_cap, n_sph
 
 template <typename T>
 inline size_t lds_bytes(int epg, int nt, int max_cap, int max_sph, int n_obs, bool rays) {
