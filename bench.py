@@ -7,7 +7,8 @@ bench.py -- env-steps/s of the batched docking3d step() on N MI355X (BASELINE.js
       bench.py --gpus N --steps K --warmup W
 
 A "step" is one launch of the fused HIP step kernel over this rank's envs (weak scaling: the per-GPU env count is
-fixed), followed -- for N > 1 -- by one RCCL all-gather of [obs | reward | done] over xGMI so that a single learner
+fixed; at N = 1 the K launches of a region are queued by one dockauv_step_sequence call), followed -- for N > 1 --
+by one RCCL all-gather of [obs | reward | done] over xGMI so that a single learner
 sees all observations.  Inputs (actions) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Workloads (--config):
@@ -147,7 +148,20 @@ def main():
     stepper = ShardedStepper(N, n_obs + 2, step_fn, dev, world=world, rank=rank, overlap=not args.no_overlap)
     stepper.use_dist = use_dist
 
+    # Single GPU, no collective: the K steps of a region are queued by ONE host call (dockauv_step_sequence: K
+    # launches of the same kernel, step i reading actions[i % RING]), so that a 6 us kernel is not paced by ~7 us of
+    # Python per step.  With a collective in the loop the steps are issued one by one (the gather sits between them).
+    seq_cache = {}
+
     def run(n, i0=0):
+        if not use_dist:
+            key = (n, i0 % RING)
+            if key not in seq_cache:
+                out_ptr = stepper.local_slice(stepper.bufs[0]).data_ptr()
+                seq_cache[key] = env.make_step_sequence([actions[i % RING].data_ptr() for i in range(i0, i0 + n)],
+                                                        [out_ptr] * n, packed=True)
+            env.run_step_sequence(seq_cache[key], stream=stream)
+            return
         for i in range(i0, i0 + n):
             stepper.step(actions[i % RING])
         stepper.wait()

@@ -92,6 +92,7 @@ SYMBOLS = [
     ("dockauv_get_field", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     ("dockauv_reset_envs", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("dockauv_step", C.c_int, [C.c_void_p, C.POINTER(StepIO), C.c_void_p]),
+    ("dockauv_step_sequence", C.c_int, [C.c_void_p, C.POINTER(StepIO), C.c_int, C.c_void_p]),
     ("dockauv_step_host", C.c_int, [C.c_void_p, C.POINTER(StepIO)]),
     ("dockauv_synchronize", C.c_int, [C.c_void_p]),
     ("dockauv_time_steps", C.c_int, [C.c_void_p, C.POINTER(StepIO), C.c_void_p, C.c_int, C.POINTER(C.c_double)]),

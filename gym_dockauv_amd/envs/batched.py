@@ -466,6 +466,25 @@ class BatchedDocking3d:
         rc = self._lib.dockauv_step(self._handle, C.byref(io), C.c_void_p(stream or None))
         _capi.check(self._lib, self._handle, rc, "dockauv_step")
 
+    def make_step_sequence(self, actions_ptrs, obs_ptrs, packed: bool = True):
+        """Prepare an open-loop sequence of steps on device pointers (step i reads actions_ptrs[i], writes
+        obs_ptrs[i]); run it with run_step_sequence().  packed as in step_device."""
+        n = len(actions_ptrs)
+        if len(obs_ptrs) != n:
+            raise ValueError("actions_ptrs and obs_ptrs must have the same length")
+        if not packed:
+            raise ValueError("make_step_sequence writes packed [obs | reward | done] rows")
+        ios = (_capi.StepIO * n)()
+        for i in range(n):
+            ios[i].actions, ios[i].obs = actions_ptrs[i], obs_ptrs[i]
+            ios[i].pack_reward_done = 1
+        return ios
+
+    def run_step_sequence(self, ios, stream: int = 0) -> None:
+        """Queue every step of a prepared sequence back-to-back on `stream` (asynchronous, one host call)."""
+        rc = self._lib.dockauv_step_sequence(self._handle, ios, len(ios), C.c_void_p(stream or None))
+        _capi.check(self._lib, self._handle, rc, "dockauv_step_sequence")
+
     def time_steps_device(self, actions_ptr: int, obs_ptr: int, reward_ptr: int = 0, done_ptr: int = 0, steps: int = 1,
                           stream: int = 0, packed: bool = False) -> float:
         """Average KERNEL duration in microseconds from per-dispatch HIP events on `stream` (bench.py)."""

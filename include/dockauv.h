@@ -193,6 +193,10 @@ int dockauv_reset_envs(dockauv_handle h, int first, int count);
 
 /* BaseDocking3d.step (docking3d.py:346-402) for all envs of the handle; device pointers, asynchronous on stream */
 int dockauv_step(dockauv_handle h, const dockauv_step_io* io, void* hip_stream);
+/* `n` consecutive steps, step i with ios[i] (device pointers), queued back-to-back on `hip_stream` by one call:
+ * an open-loop action sequence (the manual / scripted loops of train.py:108-117, 238) without a host round trip per
+ * step.  Equivalent to n calls of dockauv_step. */
+int dockauv_step_sequence(dockauv_handle h, const dockauv_step_io* ios, int n, void* hip_stream);
 /* same with host pointers (staged through the library's pinned buffers; synchronous) */
 int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io);
 /* block until everything queued on the handle's last-used stream is done */

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 for cfg in "3 65536" "4 32768" "4 262144" "5 65536"; do
   set -- $cfg
-  for th in 64 256; do
+  for th in 256 512; do
     python bench.py --config $1 --envs $2 --threads $th --steps 100 --warmup 10 --no-cpu --no-sweep 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']

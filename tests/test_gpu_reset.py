@@ -117,3 +117,34 @@ def test_tail_group_and_large_batch():
     finally:
         small.close()
         big.close()
+
+
+@pytest.mark.gpu
+def test_step_sequence_equals_single_steps():
+    """dockauv_step_sequence(n) == n x dockauv_step on the same inputs, bit for bit (same kernel, same order)."""
+    import torch
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    N, K = 777, 6
+    dev = torch.device("cuda", 0)
+    outs = []
+    for mode in ("single", "sequence"):
+        env = BatchedDocking3d(num_envs=N, scenario="ObstaclesCurrentDocking3d", precision="f32", reset_mode="device",
+                               device_seed=99, rng="batched")
+        env._gen = np.random.default_rng(3)
+        env.reset()
+        g = torch.Generator(device=dev)
+        g.manual_seed(5)
+        acts = torch.rand((K, N, env.n_u), device=dev, generator=g) * 2 - 1
+        out = torch.zeros((K, N, env.n_observations + 2), device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        if mode == "single":
+            for k in range(K):
+                env.step_device(acts[k].data_ptr(), out[k].data_ptr(), stream=stream, packed=True)
+        else:
+            ios = env.make_step_sequence([acts[k].data_ptr() for k in range(K)], [out[k].data_ptr() for k in range(K)])
+            env.run_step_sequence(ios, stream=stream)
+        torch.cuda.synchronize()
+        outs.append((out.cpu().numpy(), env.state.copy()))
+        env.close()
+    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True)
+    assert np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
