@@ -1,0 +1,21 @@
+"""PCIe-inclusive rate of the host-pointer entry point (dockauv_step_host: actions H2D, kernel, obs/reward/done D2H,
+synchronous) -- the number DESIGN.md quotes next to the device-resident one.  Never bench.py's `value`."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from gym_dockauv_amd.envs.batched import BatchedDocking3d
+for n in (4096, 65536):
+    wl = bench.workload(2, n)
+    env = BatchedDocking3d(wl["cfg"], num_envs=n, scenario=wl["scenario"], precision="f32", reset_mode="device", rng="batched")
+    env.reset()
+    a = np.random.default_rng(0).uniform(-1, 1, (16, n, env.n_u)).astype(np.float32)
+    for k in range(20):
+        env.step(a[k % 16])
+    t0 = time.perf_counter()
+    K = 200
+    for k in range(K):
+        env.step(a[k % 16])
+    dt = time.perf_counter() - t0
+    print(f"host-pointer path, config 2, N={n}: {dt / K * 1e6:.1f} us/step = {n * K / dt:.3e} env-steps/s (PCIe + Python inclusive)")
+    env.close()

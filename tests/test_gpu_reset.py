@@ -148,3 +148,38 @@ def test_step_sequence_equals_single_steps():
         env.close()
     assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True)
     assert np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_torch_env_matches_host_path():
+    """TorchDocking3d (device pointers, packed rows) == BatchedDocking3d.step (host pointers) on the same seeds."""
+    import torch
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    from gym_dockauv_amd.envs.torch_env import TorchDocking3d
+    N, K = 300, 25
+    tenv = TorchDocking3d(num_envs=N, scenario="CapsuleCurrentDocking3d", device_seed=11)
+    henv = BatchedDocking3d(num_envs=N, scenario="CapsuleCurrentDocking3d", precision="f32", reset_mode="device",
+                            device_seed=11, rng="batched")
+    try:
+        tenv.batch._gen = np.random.default_rng(8)
+        henv._gen = np.random.default_rng(8)
+        o = tenv.reset()
+        henv.reset()
+        assert o.shape == (N, tenv.n_obs) and not bool(o.any())
+        g = torch.Generator(device=tenv.device)
+        g.manual_seed(1)
+        n_done = 0
+        for k in range(K):
+            a = torch.rand((N, tenv.n_u), device=tenv.device, generator=g) * 2 - 1
+            obs, rew, done = tenv.step(a, want_terminal_obs=True)
+            ho, hr, hd, infos = henv.step(a.cpu().numpy())
+            assert np.array_equal(obs.cpu().numpy(), ho)
+            assert np.array_equal(rew.cpu().numpy(), hr)
+            assert np.array_equal(done.cpu().numpy(), hd)
+            for i in np.flatnonzero(hd):
+                assert np.array_equal(tenv.terminal_observation[i].cpu().numpy(), infos[i]["terminal_observation"])
+            n_done += int(hd.sum())
+        assert n_done > 0, "the run must cover auto-resets"
+    finally:
+        tenv.close()
+        henv.close()
