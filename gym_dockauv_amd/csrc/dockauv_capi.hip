@@ -54,6 +54,15 @@ struct dockauv_env_s {
     void* d_nav = nullptr;
     void* d_raydist = nullptr;
     float* d_termobs = nullptr;
+    // pinned host mirrors of the above (dockauv_step_host), allocated on first use
+    struct Pinned {
+        void* actions = nullptr; void* noise = nullptr; float* obs = nullptr; void* reward = nullptr;
+        uint8_t* done = nullptr; void* terms = nullptr; uint8_t* cond = nullptr; void* nav = nullptr;
+        void* raydist = nullptr; float* termobs = nullptr;
+        bool ready = false;
+    } pin;
+    std::vector<void*> pinned_allocs;
+    hipStream_t host_stream = nullptr;
 };
 
 namespace {
@@ -444,6 +453,8 @@ int dockauv_destroy(dockauv_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (void* p : h->allocs) (void)hipFree(p);
+    for (void* p : h->pinned_allocs) (void)hipHostFree(p);
+    if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
     delete h;
     return 0;
 }
@@ -555,14 +566,54 @@ int dockauv_step_sequence(dockauv_handle h, const dockauv_step_io* ios, int n, v
     return 0;
 }
 
+namespace {
+int pinned_alloc(dockauv_handle h, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 64;
+    hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(h, DOCKAUV_E_HIP, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    h->pinned_allocs.push_back(*p);
+    return 0;
+}
+
+int ensure_pinned(dockauv_handle h) {
+    if (h->pin.ready) return 0;
+    const size_t N = (size_t)h->cfg.n_envs, t = h->tsz;
+    int rc;
+    if ((rc = pinned_alloc(h, &h->pin.actions, N * h->n_u_max * t))) return rc;
+    if ((rc = pinned_alloc(h, &h->pin.noise, N * t))) return rc;
+    if ((rc = pinned_alloc(h, (void**)&h->pin.obs, N * h->n_obs * 4))) return rc;
+    if ((rc = pinned_alloc(h, &h->pin.reward, N * t))) return rc;
+    if ((rc = pinned_alloc(h, (void**)&h->pin.done, N))) return rc;
+    if ((rc = pinned_alloc(h, &h->pin.terms, N * kNRew * t))) return rc;
+    if ((rc = pinned_alloc(h, (void**)&h->pin.cond, N))) return rc;
+    if ((rc = pinned_alloc(h, &h->pin.nav, N * 4 * t))) return rc;
+    if ((rc = pinned_alloc(h, &h->pin.raydist, N * h->n_rays * t))) return rc;
+    if ((rc = pinned_alloc(h, (void**)&h->pin.termobs, N * h->n_obs * 4))) return rc;
+    HIP_TRY(h, hipStreamCreate(&h->host_stream));   // blocking stream: ordered after the null-stream copies of set_field / reset_envs
+    h->pin.ready = true;
+    return 0;
+}
+}  // namespace
+
+// Host-pointer step: the caller's (pageable) arrays are staged through pinned mirrors so that every transfer is one
+// asynchronous DMA on the library's stream: actions up, kernel, requested outputs down, ONE synchronisation.
 int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io) {
     if (!h || !io) return fail(h, DOCKAUV_E_INVALID, "null argument");
     if (!io->actions || !io->obs || !io->reward || !io->done) return fail(h, DOCKAUV_E_INVALID, "actions/obs/reward/done must not be NULL");
     if (io->pack_reward_done) return fail(h, DOCKAUV_E_INVALID, "pack_reward_done is a device-pointer feature (dockauv_step)");
     HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_pinned(h);
+    if (rc) return rc;
+    // work queued by the caller on another stream (dockauv_step) must be visible first
+    if (h->last_stream && h->last_stream != h->host_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream));
     const size_t N = (size_t)h->cfg.n_envs, t = h->tsz;
-    HIP_TRY(h, hipMemcpy(h->d_actions, io->actions, N * h->n_u_max * t, hipMemcpyHostToDevice));
-    if (io->noise) HIP_TRY(h, hipMemcpy(h->d_noise, io->noise, N * t, hipMemcpyHostToDevice));
+    hipStream_t s = h->host_stream;
+    std::memcpy(h->pin.actions, io->actions, N * h->n_u_max * t);
+    HIP_TRY(h, hipMemcpyAsync(h->d_actions, h->pin.actions, N * h->n_u_max * t, hipMemcpyHostToDevice, s));
+    if (io->noise) {
+        std::memcpy(h->pin.noise, io->noise, N * t);
+        HIP_TRY(h, hipMemcpyAsync(h->d_noise, h->pin.noise, N * t, hipMemcpyHostToDevice, s));
+    }
     dockauv_step_io d{};
     d.actions = h->d_actions;
     d.noise = io->noise ? h->d_noise : nullptr;
@@ -574,17 +625,53 @@ int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io) {
     d.nav = io->nav ? h->d_nav : nullptr;
     d.ray_dist = io->ray_dist ? h->d_raydist : nullptr;
     d.terminal_obs = io->terminal_obs ? h->d_termobs : nullptr;
-    int rc = launch(h, &d, nullptr);
+    rc = launch(h, &d, s);
     if (rc) return rc;
-    HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(io->obs, h->d_obs, N * h->n_obs * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(io->reward, h->d_reward, N * t, hipMemcpyDeviceToHost));
-    HIP_TRY(h, hipMemcpy(io->done, h->d_done, N, hipMemcpyDeviceToHost));
-    if (io->reward_terms) HIP_TRY(h, hipMemcpy(io->reward_terms, h->d_terms, N * kNRew * t, hipMemcpyDeviceToHost));
-    if (io->conditions) HIP_TRY(h, hipMemcpy(io->conditions, h->d_cond, N, hipMemcpyDeviceToHost));
-    if (io->nav) HIP_TRY(h, hipMemcpy(io->nav, h->d_nav, N * 4 * t, hipMemcpyDeviceToHost));
-    if (io->ray_dist) HIP_TRY(h, hipMemcpy(io->ray_dist, h->d_raydist, N * h->n_rays * t, hipMemcpyDeviceToHost));
-    if (io->terminal_obs) HIP_TRY(h, hipMemcpy(io->terminal_obs, h->d_termobs, N * h->n_obs * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpyAsync(h->pin.obs, h->d_obs, N * h->n_obs * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->pin.reward, h->d_reward, N * t, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->pin.done, h->d_done, N, hipMemcpyDeviceToHost, s));
+    if (io->reward_terms) HIP_TRY(h, hipMemcpyAsync(h->pin.terms, h->d_terms, N * kNRew * t, hipMemcpyDeviceToHost, s));
+    if (io->conditions) HIP_TRY(h, hipMemcpyAsync(h->pin.cond, h->d_cond, N, hipMemcpyDeviceToHost, s));
+    if (io->nav) HIP_TRY(h, hipMemcpyAsync(h->pin.nav, h->d_nav, N * 4 * t, hipMemcpyDeviceToHost, s));
+    if (io->ray_dist) HIP_TRY(h, hipMemcpyAsync(h->pin.raydist, h->d_raydist, N * h->n_rays * t, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if (io->terminal_obs) {
+        // terminal observations only exist for envs that finished in this step: fetch the rows of those envs only
+        // (typically none or a few; the buffer is as large as the observations themselves)
+        const uint8_t* dn = h->pin.done;
+        size_t first = N, last = 0, runs = 0;
+        for (size_t i = 0; i < N; ++i)
+            if (dn[i]) {
+                if (first == N) first = i;
+                if (i == 0 || !dn[i - 1]) ++runs;
+                last = i;
+            }
+        if (runs > 0) {
+            if (runs <= 4) {
+                for (size_t i = first; i <= last;) {
+                    if (!dn[i]) { ++i; continue; }
+                    size_t j = i;
+                    while (j <= last && dn[j]) ++j;
+                    HIP_TRY(h, hipMemcpyAsync(h->pin.termobs + i * h->n_obs, h->d_termobs + i * h->n_obs,
+                                              (j - i) * h->n_obs * 4, hipMemcpyDeviceToHost, s));
+                    i = j;
+                }
+            } else {   // many scattered rows: one DMA over the span beats a launch per row
+                HIP_TRY(h, hipMemcpyAsync(h->pin.termobs + first * h->n_obs, h->d_termobs + first * h->n_obs,
+                                          (last - first + 1) * h->n_obs * 4, hipMemcpyDeviceToHost, s));
+            }
+            HIP_TRY(h, hipStreamSynchronize(s));
+            for (size_t i = first; i <= last; ++i)
+                if (dn[i]) std::memcpy(io->terminal_obs + i * h->n_obs, h->pin.termobs + i * h->n_obs, (size_t)h->n_obs * 4);
+        }
+    }
+    std::memcpy(io->obs, h->pin.obs, N * h->n_obs * 4);
+    std::memcpy(io->reward, h->pin.reward, N * t);
+    std::memcpy(io->done, h->pin.done, N);
+    if (io->reward_terms) std::memcpy(io->reward_terms, h->pin.terms, N * kNRew * t);
+    if (io->conditions) std::memcpy(io->conditions, h->pin.cond, N);
+    if (io->nav) std::memcpy(io->nav, h->pin.nav, N * 4 * t);
+    if (io->ray_dist) std::memcpy(io->ray_dist, h->pin.raydist, N * h->n_rays * t);
     return 0;
 }
 

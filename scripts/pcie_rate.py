@@ -17,5 +17,13 @@ for n in (4096, 65536):
     for k in range(K):
         env.step(a[k % 16])
     dt = time.perf_counter() - t0
+    import ctypes as C
+    aa = np.ascontiguousarray(a[0], dtype=np.float32)
+    io = env._io(aa, None, False)
+    t1 = time.perf_counter()
+    for k in range(K):
+        env._lib.dockauv_step_host(env._handle, C.byref(io))
+    dt_c = time.perf_counter() - t1
+    print(f"  dockauv_step_host alone: {dt_c / K * 1e6:.1f} us/step = {n * K / dt_c:.3e} env-steps/s")
     print(f"host-pointer path, config 2, N={n}: {dt / K * 1e6:.1f} us/step = {n * K / dt:.3e} env-steps/s (PCIe + Python inclusive)")
     env.close()
