@@ -124,12 +124,12 @@ struct DevArgs {
 // LDS hand-over layout between the env phase and the ray stage
 constexpr int kCapFields = 10;   // body-frame unit axis d(3), oa_perp(3), oa_par, |ba|, r^2, oa_par - |ba|
 constexpr int kSphFields = 4;    // body-frame origin - centre (3), r^2
-constexpr int kPoseFields = 2;   // n_cap, n_sph
+constexpr int kPoseFields = 14;  // n_cap, n_sph, position (3), body -> NED rotation (9)
 constexpr int kHxFields = 16;    // env phase -> bookkeeper wave: state (12), V_c, action penalty, |euler_dot|^2, collision
 
 template <typename T>
 inline size_t lds_bytes(int epg, int nt, int max_cap, int max_sph, int n_obs, bool rays) {
-    size_t t_elems = rays ? (size_t)epg * (kPoseFields + kCapFields * max_cap + kSphFields * max_sph + 2 * (nt / epg)) : 0;
+    size_t t_elems = rays ? (size_t)epg * (kPoseFields + kCapFields * max_cap + kSphFields * max_sph + 3 * (nt / epg)) : 0;
     if (nt / epg >= 2) t_elems += (size_t)epg * kHxFields;
     size_t bytes = t_elems * sizeof(T);
     bytes = (bytes + 15) & ~(size_t)15;
