@@ -52,6 +52,11 @@ def workload(config_id: int, envs: int):
     if config_id == 5:
         cfg["t_step_size"] = 0.02
         n = envs or 65536
+        if os.environ.get("DOCKAUV_CONFIG5_SORTED") == "1":
+            # vehicle-sorted layout: first half BlueROV2, second half LAUV -> every wave but one is homogeneous
+            return dict(cfg=cfg, scenario="ObstaclesCurrentDocking3d", envs=n,
+                        vehicles=["BlueROV2"] * (n // 2) + ["LAUV"] * (n - n // 2),
+                        name="config5: BlueROV2/LAUV vehicle-sorted, ObstaclesCurrentDocking3d, h=0.02")
         return dict(cfg=cfg, scenario="ObstaclesCurrentDocking3d", envs=n,
                     vehicles=["BlueROV2" if i % 2 == 0 else "LAUV" for i in range(n)],
                     name="config5: BlueROV2/LAUV interleaved, ObstaclesCurrentDocking3d, h=0.02")
