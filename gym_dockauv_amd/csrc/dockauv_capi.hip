@@ -33,6 +33,7 @@ struct dockauv_env_s {
     size_t tsz = 4;
     long S = 0;   // SoA row stride (envs rounded up to 64)
     int n_rays = 0, n_red = 0, n_obs = 0, n_u_max = 0;
+    double fan_cos = -1.0, fan_sin = 0.0, sum_beta = 0.0;   // cone around the ray fan, sum of the ray weights
     int vk = VK_JOY;
     bool has_rays = false;
     bool sym = false;
@@ -176,6 +177,12 @@ void fill_env(EnvP<T>& e, const dockauv_env_s& h) {
     e.ray_max = (T)c.radar_max_dist;
     e.alpha_max = (T)c.radar_alpha_max;
     e.beta_max = (T)c.radar_beta_max;
+    int pad = 1;
+    while (pad < h.n_rays) pad *= 2;
+    e.ray_pad = pad;
+    e.fan_cos = (T)h.fan_cos;
+    e.fan_sin = (T)h.fan_sin;
+    e.sum_beta = (T)h.sum_beta;
 }
 
 // structural fast path of kinetics_: x_G = y_G = x_B = y_B = 0, diagonal I_b, M^-1 = diagonal + (0,4),(1,3) couplings
@@ -330,6 +337,21 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
     h->tsz = h->f64 ? 8 : 4;
     h->S = ((long)c.n_envs + 63) / 64 * 64;
     h->n_rays = c.n_v * c.n_h;
+    {
+        // circular cone around the body x axis that contains every ray of the fan, widened by 1e-3 rad (used to skip
+        // obstacles no ray can reach), and the sum of the obstacle-avoidance weights
+        double min_bx = 1.0, sb = 0.0;
+        for (int r = 0; r < h->n_rays; ++r) {
+            const double* q = c.ray_table + (size_t)r * 4;
+            const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+            min_bx = std::min(min_bx, q[0] / n);
+            sb += q[3];
+        }
+        const double half = std::min(std::acos(std::max(-1.0, std::min(1.0, min_bx))) + 1e-3, 3.14159265358979);
+        h->fan_cos = std::cos(half);
+        h->fan_sin = std::sin(half);
+        h->sum_beta = sb;
+    }
     const int blk = c.blocksize_reduce;
     h->n_red = ((c.n_v + blk - 1) / blk) * ((c.n_h + blk - 1) / blk);
     h->n_obs = DOCKAUV_N_OBS_BASE + h->n_red;

@@ -53,6 +53,11 @@ struct EnvP {
     T w_done[5];
     T w_act[kMaxU];      // action_reward_factors[i]
     T ray_max, alpha_max, beta_max;
+    // ray stage with one lane per ray (fans of <= 64 rays): lanes per env (power of two >= n_rays), the circular cone
+    // that contains the fan (cos / sin of its half-angle, widened by 1e-3 rad), the sum of the obstacle-avoidance
+    // weights over all rays
+    int ray_pad;
+    T fan_cos, fan_sin, sum_beta;
 };
 
 // All per-env arrays are struct-of-arrays: element (field k, env i) lives at base[k * stride + i], stride = n_envs
@@ -124,7 +129,7 @@ struct DevArgs {
 // LDS hand-over layout between the env phase and the ray stage
 constexpr int kCapFields = 10;   // body-frame unit axis d(3), oa_perp(3), oa_par, |ba|, r^2, oa_par - |ba|
 constexpr int kSphFields = 4;    // body-frame origin - centre (3), r^2
-constexpr int kPoseFields = 14;  // n_cap, n_sph, position (3), body -> NED rotation (9)
+constexpr int kPoseFields = 16;  // n_cap, n_sph, position (3), body -> NED rotation (9), may-be-hit bit masks (capsules, spheres)
 constexpr int kHxFields = 16;    // env phase -> bookkeeper wave: state (12), V_c, action penalty, |euler_dot|^2, collision
 
 template <typename T>
