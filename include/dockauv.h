@@ -102,8 +102,8 @@ typedef struct dockauv_config {
     int32_t max_spheres;           /* per-env sphere slots, 0..DOCKAUV_MAX_SPHERES */
     int32_t n_v, n_h;              /* ray fan: vertical x horizontal rays (sensor.py:56-63) */
     int32_t blocksize_reduce;      /* "blocksize_reduce" (sensor.py:136-137) */
-    int32_t envs_per_group;        /* launch tuning: 0 = auto */
-    int32_t threads_per_group;     /* launch tuning: 0 = auto */
+    int32_t envs_per_group;        /* 0 = auto (64); -1 = test hook: general (non-structural) kinetics expressions */
+    int32_t threads_per_group;     /* 0 = auto; 64/128 without obstacles, 64/256/512 with: waves per 64-env group */
     uint64_t seed;                 /* DOCKAUV_RESET_DEVICE: counter-RNG key */
     double t_step_size;            /* "t_step_size" */
     double lowpass_T1;             /* 0.2 (objects/auvsim.py:40) */
