@@ -102,10 +102,15 @@ def test_random_obstacle_geometry_vs_oracle(precision):
         np.testing.assert_allclose(obs[ok], obs_ref[ok], atol=2e-5)
 
 
-@pytest.mark.parametrize("blk,ray_per_deg_deg,alpha_deg,beta_deg", [(1, 10, 20, 40), (3, 10, 60, 80), (2, 5, 20, 30), (4, 15, 60, 90)])
+@pytest.mark.parametrize("blk,ray_per_deg_deg,alpha_deg,beta_deg",
+                         [(1, 10, 20, 40), (3, 10, 60, 80), (2, 5, 20, 30), (4, 15, 60, 90),
+                          (2, 5, 40, 60),      # 9 x 13 = 117 rays: the lane = env / wave = cell stage of fans wider than 64 rays
+                          (2, 10, 10, 30),     # 2 x 4 = 8 rays: 8 envs per wave pass
+                          (1, 20, 20, 20)])    # 2 x 2 = 4 rays: 16 envs per wave pass
 def test_fan_and_block_sizes_vs_oracle(blk, ray_per_deg_deg, alpha_deg, beta_deg):
     """Ray fans and block-max sizes other than the default 7 x 9 / 2 x 2 (cells with 1, 9 and 16 rays, ragged edge
-    cells, fans wider than the 4-ray chunk of the ray stage) against the oracle, float64, a few free-running steps."""
+    cells, 1 to 117 rays: both ray-stage mappings, 1 to 64 envs per wave pass) against the oracle, float64, a few
+    free-running steps."""
     import copy
     from gym_dockauv_amd.config.env_config import BASE_CONFIG
     from gym_dockauv_amd.envs.batched import BatchedDocking3d
