@@ -15,8 +15,10 @@ stream, including the one ``normal`` draw ``Current.sim`` burns per step (object
 ``reset(seed=s)`` reproduces the reference's initial conditions.  For throughput use ``BatchedDocking3d`` directly:
 one launch steps 10^3-10^6 envs, one env per launch wastes the GPU.
 
-``render`` and the pickle storages are not on the accelerated path: ``render`` raises,
-``save_full_data_storage`` is a no-op.
+``render`` is not on the accelerated path and raises.  The episode / full-run pickle storages
+(utils/datastorage.py) are host-side logging: off by default (they write files), switched on with the config key
+``"data_storage": True``; then they are fed and saved exactly where the reference does it
+(``gym_dockauv_amd/utils/datastorage.py``).
 """
 from __future__ import annotations
 
@@ -28,6 +30,7 @@ import numpy as np
 
 from .. import _capi
 from ..config.env_config import BASE_CONFIG
+from ..utils.datastorage import EpisodeDataStorage, FullDataStorage
 from .batched import META_DATA_DONE, META_DATA_REWARD, BatchedDocking3d
 
 try:                                  # gym is optional: subclass gym.Env when it is there (SB3 checks isinstance)
@@ -134,6 +137,16 @@ class BaseDocking3d(_EnvBase):
         self.episode = 0
         self.t_total_steps = 0
         self._zero_episode()
+        # storages (docking3d.py:207-212); opt-in here because they write pickles under save_path_folder
+        self.save_path_folder = self.config.get("save_path_folder", "logs")
+        self.interval_datastorage = int(self.config.get("interval_datastorage", 100))
+        self.data_storage = bool(self.config.get("data_storage", False))
+        self.episode_data_storage = None
+        self.full_data_storage = None
+        self.nu_c = np.zeros(6)
+        if self.data_storage:
+            self.full_data_storage = FullDataStorage()
+            self.full_data_storage.set_up_full_storage(env=self, path_folder=self.save_path_folder, title=self.title)
 
     # ------------------------------------------------------------------------------------------ bookkeeping
     def _zero_episode(self) -> None:
@@ -169,17 +182,52 @@ class BaseDocking3d(_EnvBase):
     # ------------------------------------------------------------------------------------------ gym.Env
     def reset(self, seed: Optional[int] = None, return_info: bool = False, options=None):
         """docking3d.py:222-322.  Returns the all-zero observation, like the reference (observe() is not called)."""
+        return_info_dict = dict(self.info)
+        if self.data_storage:
+            # docking3d.py:252-259: close the running episode's storage, then the run-level one
+            if self.episode_data_storage and (self.episode % self.interval_datastorage == 0 or self.episode == 1):
+                self.episode_data_storage.update(self.nu_c)
+                self.episode_data_storage.save()
+            self.episode_data_storage = None
+            if self.episode != 0:
+                self.full_data_storage.update()
         self._batch.reset(seed=None if seed is None else [int(seed)])
         self.episode += 1
         self._zero_episode()
+        if self.data_storage:
+            self.nu_c = self._current_body(self.auv.attitude)
+            if self.episode % self.interval_datastorage == 0 or self.episode == 1:      # docking3d.py:314-317
+                self.init_episode_storage()
         if return_info:
-            return self.observation, {}
+            return self.observation, return_info_dict
         return self.observation
+
+    # ------------------------------------------------------------------------------------------ logging (host side)
+    def _current_body(self, attitude: np.ndarray) -> np.ndarray:
+        """nu_c = [R(Theta)^T v_c^n, 0, 0, 0] (objects/current.py:33-76) from the device's current fields; for the logs."""
+        vc, _, _, al, be = self._batch.get_field(_capi.F_CURRENT)[0]
+        phi, th, psi = attitude
+        cf, sf, ct, st_, cp, sp = np.cos(phi), np.sin(phi), np.cos(th), np.sin(th), np.cos(psi), np.sin(psi)
+        R = np.array([[cp * ct, -sp * cf + cp * st_ * sf, sp * sf + cp * cf * st_],
+                      [sp * ct, cp * cf + sf * st_ * sp, -cp * sf + st_ * sp * cf],
+                      [-st_, ct * sf, ct * cf]])
+        v_n = vc * np.array([np.cos(al) * np.cos(be), np.sin(be), np.sin(al) * np.cos(be)])
+        return np.concatenate([R.T @ v_n, np.zeros(3)])
+
+    def init_episode_storage(self) -> None:
+        """docking3d.py:675-685."""
+        shapes = [{"type": "Capsule", "position": 0.5 * (c[0:3] + c[3:6]), "vec_bot": c[0:3].copy(), "vec_top": c[3:6].copy(),
+                   "radius": float(c[6])} for c in self.capsules]
+        shapes.append({"type": "Sphere", "position": self.goal_location.copy(), "radius": 0.15})
+        self.episode_data_storage = EpisodeDataStorage()
+        self.episode_data_storage.set_up_episode_storage(path_folder=self.save_path_folder, env=self, nu_c_init=self.nu_c,
+                                                         shapes=shapes, title=self.title, episode=self.episode)
 
     def step(self, action: np.ndarray):
         """docking3d.py:346-402."""
         t0 = time.perf_counter()
         a = np.asarray(action, dtype=np.float64).reshape(1, -1)
+        att_pre = self.auv.attitude if self.episode_data_storage else None
         obs, rew, done, _ = self._batch.step(a, extras=True)
         b = self._batch
         self.observation = obs[0]
@@ -208,13 +256,17 @@ class BaseDocking3d(_EnvBase):
                      "goal_reached": self.goal_reached,
                      "simulation_time": time.perf_counter() - t0,
                      "delta_d": self.delta_d}
+        if self.episode_data_storage:                       # docking3d.py:363-364
+            self.nu_c = self._current_body(att_pre)         # current in the body frame at the PRE-step attitude (Q2)
+            self.episode_data_storage.update(self.nu_c)
         return self.observation, self.last_reward, self.done, self.info
 
     def render(self, mode="human", real_time=False):
         raise NotImplementedError("rendering (utils/plotutils.py) is outside the accelerated path: SURVEY.md section 2")
 
-    def save_full_data_storage(self) -> None:
-        """The reference pickles its FullDataStorage here (docking3d.py:669-673); logging is not on this path."""
+    def save_full_data_storage(self):
+        """docking3d.py:669-673; returns the file name (None when ``data_storage`` is off)."""
+        return self.full_data_storage.save() if self.full_data_storage is not None else None
 
     def close(self) -> None:
         self._batch.close()

@@ -85,3 +85,68 @@ def test_every_env_class_steps_and_terminates():
             assert not obs2.any() and env.t_steps == 0 and env.episode == 2
         finally:
             env.close()
+
+
+def test_array_list_and_storage_schema(tmp_path):
+    """ArrayList growth and the pickle schema of both storages, fed from a stand-in env (no GPU needed)."""
+    import pickle
+    import types
+    from gym_dockauv_amd.utils.datastorage import ArrayList, EpisodeDataStorage, FullDataStorage
+    a = ArrayList(np.arange(3.0))
+    for i in range(450):
+        a.add_row(np.full(3, i))
+    assert a.get_nparray().shape == (451, 3) and a[450, 0] == 449 and a.capacity == 1600
+    auv = types.SimpleNamespace(state=np.zeros(12), u=np.zeros(6), u_bound=np.array([[-1.0, 1.0]] * 6), safety_radius=1, name="x")
+    env = types.SimpleNamespace(auv=auv, radar=types.SimpleNamespace(end_pos_n=np.zeros((63, 3))), cum_reward_arr=np.zeros(13),
+                                last_reward_arr=np.zeros(13), observation=np.zeros(36, np.float32), meta_data_reward=["r"] * 13,
+                                meta_data_observation=["o"] * 36, n_cont_rewards=8, t_step_size=0.1, info={"done": True})
+    ep = EpisodeDataStorage()
+    ep.set_up_episode_storage(str(tmp_path), env, np.zeros(6), shapes=[{"type": "Sphere"}], title="t", episode=1)
+    for _ in range(5):
+        ep.update(np.ones(6))
+    d = pickle.load(open(ep.save(), "rb"))
+    assert set(d) == {"vehicle", "radar", "nu_c", "shapes", "title", "episode", "step_size", "cum_rewards", "rewards",
+                      "meta_data_reward", "n_cont_rewards", "observation", "meta_data_observation"}     # datastorage.py:254-271
+    assert set(d["vehicle"]) == {"object", "states", "states_dot", "u"}
+    assert d["vehicle"]["states"].shape == (6, 12) and d["radar"].shape == (6, 63, 3) and d["nu_c"].shape == (6, 6)
+    assert d["rewards"].shape == (6, 13) and d["observation"].shape == (6, 36) and d["vehicle"]["u"].shape == (6, 6)
+    full = FullDataStorage()
+    full.set_up_full_storage(env, str(tmp_path), "t")
+    full.update()
+    f = pickle.load(open(full.save(), "rb"))
+    assert set(f) == {"title", "cum_rewards", "rewards", "meta_data_reward", "n_cont_rewards", "infos"}  # datastorage.py:56-63
+    assert f["cum_rewards"].shape == (2, 13) and f["infos"] == [{"done": True}]
+
+
+@pytest.mark.gpu
+def test_data_storage_through_the_env(tmp_path):
+    """With "data_storage": True the env saves episode 1 at the next reset and the run-level storage on demand."""
+    import copy
+    import glob
+    import pickle
+    from gym_dockauv_amd.config.env_config import BASE_CONFIG
+    from gym_dockauv_amd.envs import ObstaclesCurrentDocking3d
+    cfg = copy.deepcopy(BASE_CONFIG)
+    cfg.update(data_storage=True, save_path_folder=str(tmp_path), max_timesteps=7, title="unit")
+    env = ObstaclesCurrentDocking3d(cfg)
+    try:
+        env.reset(seed=1)
+        n = 0
+        done = False
+        while not done:
+            _, _, done, info = env.step(np.full(6, 0.3))
+            n += 1
+        env.reset()
+        files = glob.glob(str(tmp_path / "*EPISODE_1_DATA_STORAGE.pkl"))
+        assert len(files) == 1
+        d = pickle.load(open(files[0], "rb"))
+        # first row = the state at set-up, one row per step, one more from the closing update (docking3d.py:253)
+        assert d["vehicle"]["states"].shape == (n + 2, 12) and d["observation"].shape == (n + 2, 36)
+        assert d["radar"].shape == (n + 2, 63, 3) and d["step_size"] == 0.1 and d["episode"] == 1
+        assert np.isfinite(d["nu_c"]).all() and np.abs(d["nu_c"][1:, 0:3]).max() > 0        # this scenario has a current
+        assert [s["type"] for s in d["shapes"]] == ["Capsule"] * 5 + ["Sphere"]
+        np.testing.assert_allclose(d["cum_rewards"][n].sum(), info["cumulative_reward"], rtol=1e-5)
+        f = pickle.load(open(env.save_full_data_storage(), "rb"))
+        assert f["cum_rewards"].shape == (2, 13) and f["infos"][0]["t_step"] == n
+    finally:
+        env.close()
