@@ -92,6 +92,29 @@ def cpu_baseline(wl, seconds: float):
                       f"in {dt:.1f} s, uniform random actions, reset on done"}
 
 
+def cpu_baseline_all_cores(args, seconds: float):
+    """The same oracle loop in one child process per CPU of this host (independent envs, as SURVEY.md section 8d asks);
+    children never touch the GPU.  Returns (aggregate env-steps/s, processes)."""
+    import subprocess
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    procs = max(1, min(avail, 16))   # a one-GPU box's CPU share is 16 cores
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--config", str(args.config),
+           "--cpu-seconds", str(seconds)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
+    children = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(procs)]
+    total = 0.0
+    for c in children:
+        out, _ = c.communicate(timeout=seconds * 6 + 60)
+        try:
+            total += float(out.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            pass
+    return total, procs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,11 +124,15 @@ def main():
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (0 = the config's size)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)   # child of cpu_baseline_all_cores
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the all-gather with the next kernel")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--sweep", type=int, nargs="*", default=[65536, 1048576])
     args = ap.parse_args()
+    if args.cpu_worker:      # oracle loop only: no torch, no GPU
+        print(cpu_baseline(workload(args.config, 1), args.cpu_seconds)["value"])
+        return
 
     import torch
     import torch.distributed as dist
@@ -262,6 +289,9 @@ def main():
             out["sweep"] = sweep
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
+            allv, procs = cpu_baseline_all_cores(args, args.cpu_seconds)
+            out["cpu_baseline"]["all_cores_value"] = allv        # one oracle process per CPU of this host
+            out["cpu_baseline"]["all_cores"] = procs
         print(json.dumps(out), flush=True)
     env.close()
     if use_dist:
