@@ -361,10 +361,11 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
     // threads per 64-env group: the ray stage spreads over all waves of the group.  Heavy fans on small batches
     // (fewer than ~2 resident waves per SIMD at 256 threads) get 8 waves per group; measured on MI355X: LAUV,
     // 63 rays x 5 capsules, 32 768 envs: 27.5 -> 22.8 us; at 65 536+ envs 256 threads are faster.
-    // Without obstacles a second wave per group (the "bookkeeper": reward, reset, write-back) shortens the step while
-    // the chip has idle SIMDs; at very large batches one wave per group does the least total work.
+    // Without obstacles extra waves per group (bookkeeper, resetter, second observation wave: the tail of the step cut
+    // in two or four) shorten the step while the chip has idle SIMDs; at very large batches one wave per group does
+    // the least total work.
     if (c.threads_per_group > 0) h->threads = c.threads_per_group;
-    else if (!h->has_rays) h->threads = c.n_envs <= 131072 ? 128 : 64;
+    else if (!h->has_rays) h->threads = c.n_envs <= 65536 ? 256 : (c.n_envs <= 131072 ? 128 : 64);
     else h->threads = ((long)h->n_rays * (c.max_capsules + c.max_spheres) >= 256 && c.n_envs <= 32768) ? 512 : 256;
     if (c.n_vehicles == 2) {
         if (!(c.vehicle[0].kind == DOCKAUV_VEH_CONSTB && b_is_diagonal(c.vehicle[0]) && c.vehicle[1].kind == DOCKAUV_VEH_LAUV)) {

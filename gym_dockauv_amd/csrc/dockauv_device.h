@@ -130,7 +130,7 @@ struct DevArgs {
 constexpr int kCapFields = 10;   // body-frame unit axis d(3), oa_perp(3), oa_par, |ba|, r^2, oa_par - |ba|
 constexpr int kSphFields = 4;    // body-frame origin - centre (3), r^2
 constexpr int kPoseFields = 16;  // n_cap, n_sph, position (3), body -> NED rotation (9), may-be-hit bit masks (capsules, spheres)
-constexpr int kHxFields = 16;    // env phase -> bookkeeper wave: state (12), V_c, action penalty, |euler_dot|^2, collision
+constexpr int kHxFields = 21;    // env phase -> tail waves: state (12), V_c, action penalty, |euler_dot|^2, collision, nu_c (3), sin/cos psi
 
 template <typename T>
 inline size_t lds_bytes(int epg, int nt, int max_cap, int max_sph, int n_obs, bool rays) {

@@ -186,7 +186,7 @@ def test_torch_env_matches_host_path():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scenario,layouts", [("SimpleCurrentDocking3d", (64, 128)), ("ObstaclesCurrentDocking3d", (64, 256, 512))])
+@pytest.mark.parametrize("scenario,layouts", [("SimpleCurrentDocking3d", (64, 128, 256)), ("ObstaclesCurrentDocking3d", (64, 256, 512))])
 def test_wave_layouts_agree(scenario, layouts):
     """One wave per group (everything in wave 0) vs several (bookkeeper wave: reward / reset / write-back, prefetch
     waves, ray stage spread over all): the same arithmetic on the same inputs, so the same trajectories incl. in-kernel
