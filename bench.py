@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)   # child of cpu_baseline_all_cores
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the all-gather with the next kernel")
+    ap.add_argument("--gather", choices=["auto", "rccl", "p2p"], default="auto",
+                    help="N > 1: transport of the per-step gather.  auto = peer-to-peer push (dockauv_p2p_*) if it maps "
+                         "and reproduces the RCCL all-gather bit for bit during warm-up, else RCCL")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--sweep", type=int, nargs="*", default=[65536, 1048576])
     args = ap.parse_args()
@@ -148,7 +151,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("DOCKAUV_FORCE_DIST") == "1"   # the latter: 1-rank rehearsal of the RCCL path
+    saved_stdout = None
     if use_dist:
+        # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
@@ -179,6 +187,38 @@ def main():
 
     stepper = ShardedStepper(N, n_obs + 2, step_fn, dev, world=world, rank=rank, overlap=not args.no_overlap)
     stepper.use_dist = use_dist
+    transport, p2p_note, n_verify = ("rccl" if use_dist else "none"), None, 0
+    two_streams = N * (n_obs + 2) * 4 >= (2 << 20)      # P2PShardedStepper.run_sequence's own rule
+    if use_dist and args.gather in ("auto", "p2p"):
+        # peer-to-peer transport: accepted only if every rank mapped its peers AND the gathered rows of the first
+        # warm-up steps equal an RCCL all-gather of the same rows bit for bit on every rank
+        from gym_dockauv_amd.parallel import P2PShardedStepper
+        from gym_dockauv_amd._capi import DockAUVError
+        p2p = None
+        try:
+            p2p = P2PShardedStepper(N, n_obs + 2, step_fn, dev, world=world, rank=rank, overlap=not args.no_overlap)
+        except (DockAUVError, ValueError) as e:
+            p2p_note = f"p2p set-up failed: {e}"
+        if p2p is not None:
+            n_verify = max(1, min(8, args.warmup))
+            ref = torch.empty((world * N, n_obs + 2), device=dev, dtype=torch.float32)
+            ok = 1
+            for i in range(n_verify):
+                buf = p2p.step(actions[i % RING])
+                p2p.wait()
+                dist.all_gather_into_tensor(ref, p2p.rows)
+                ok &= int(torch.equal(buf.view(torch.int32), ref.view(torch.int32)))
+            ok &= int(p2p.gather.timed_out() == 0)
+            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                stepper, transport = p2p, "p2p"
+            else:
+                p2p_note = "p2p rows differed from the RCCL all-gather (or stamps timed out) during warm-up: RCCL used"
+                p2p.close()
+                p2p = None
+        if transport != "p2p" and args.gather == "p2p":
+            raise SystemExit(p2p_note)
 
     # Single GPU, no collective: the K steps of a region are queued by ONE host call (dockauv_step_sequence: K
     # launches of the same kernel, step i reading actions[i % RING]), so that a 6 us kernel is not paced by ~7 us of
@@ -194,11 +234,18 @@ def main():
                                                         [out_ptr] * n, packed=True)
             env.run_step_sequence(seq_cache[key], stream=stream)
             return
+        if transport == "p2p" and not args.no_overlap:
+            # one host call: n step kernels on the compute stream, their gathers on a second stream
+            key = (n, i0 % RING, stepper.gather.t & 1)
+            if key not in seq_cache:
+                seq_cache[key] = stepper.make_sequence(env, [actions[i % RING].data_ptr() for i in range(i0, i0 + n)])
+            stepper.run_sequence(env, seq_cache[key])
+            return
         for i in range(i0, i0 + n):
             stepper.step(actions[i % RING])
         stepper.wait()
 
-    run(args.warmup)
+    run(max(0, args.warmup - n_verify), n_verify)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -217,7 +264,7 @@ def main():
 
     # roofline of the dominant (only) kernel: per-dispatch start/stop events on the launch stream, cycling through
     # the same action ring as the timed region
-    out_l = stepper.local_slice(stepper.bufs[0])
+    out_l = stepper.rows if transport == "p2p" else stepper.local_slice(stepper.bufs[0])
     k_steps = min(args.steps, 1024)
     kernel_us = 0.0
     for i in range(k_steps):
@@ -226,6 +273,8 @@ def main():
     kernel_us /= n_timed
     torch.cuda.synchronize()
     last = stepper.bufs[0]
+    if transport == "p2p" and stepper.gather.timed_out() != 0:
+        raise SystemExit(f"rank {rank}: peer stamps timed out in the timed region (mask {stepper.gather.timed_out():#x})")
     finite = bool(torch.isfinite(last).all().item())
     n_done = int((out_l[:, n_obs + 1] > 0.5).sum().item())
 
@@ -251,6 +300,19 @@ def main():
             e2.close()
             del a2, o2
 
+    if not use_dist:
+        collective = "none"
+    elif transport == "rccl":
+        collective = ("one rccl all_gather of packed [obs|reward|done] per step"
+                      + ("" if args.no_overlap else ", overlapped with the next step's kernel"))
+    else:
+        collective = ("peer-to-peer push of packed [obs|reward|done] into every rank's gather buffer + step stamps "
+                      "(dockauv_p2p_*): one copy kernel per step, every rank holds all rows of step t "
+                      + ("before step t + 1 starts, issued step by step" if args.no_overlap else
+                         "two steps later at the latest (copy on a second stream beside the next step kernel), one host "
+                         "call per region" if two_streams else
+                         "before step t + 1 starts (same stream as the step kernel), one host call per region")
+                      + f"; checked bit-exact against an rccl all_gather on the first {n_verify} warm-up steps")
     if rank == 0:
         bytes_per_launch = ALGO_BYTES[args.config] * N
         achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
@@ -276,8 +338,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["name"], "envs_per_gpu": N, "total_envs": world * N, "n_obs": n_obs, "n_u": n_u,
                        "auto_reset": "in-kernel scenario generation (Philox4x32-10)",
-                       "collective": ("one rccl all_gather of packed [obs|reward|done] per step"
-                                      + ("" if args.no_overlap else ", overlapped with the next step's kernel")) if use_dist else "none",
+                       "collective": collective,
+                       **({"gather_note": p2p_note} if p2p_note else {}),
                        "obs_finite": finite, "done_last_step_rank0": n_done},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
@@ -292,7 +354,14 @@ def main():
             allv, procs = cpu_baseline_all_cores(args, args.cpu_seconds)
             out["cpu_baseline"]["all_cores_value"] = allv        # one oracle process per CPU of this host
             out["cpu_baseline"]["all_cores"] = procs
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)
+    if transport == "p2p":
+        stepper.close()
     env.close()
     if use_dist:
         dist.destroy_process_group()

@@ -77,6 +77,19 @@ class StepIO(C.Structure):
     ]
 
 
+P2P_HANDLE_BYTES = 64
+P2P_MAX_PEERS = 15
+
+
+class P2PPlan(C.Structure):
+    _fields_ = [
+        ("dsts", C.c_void_p * (P2P_MAX_PEERS + 1)), ("peer_slots", C.c_void_p * P2P_MAX_PEERS),
+        ("my_flags", C.c_void_p), ("status", C.c_void_p), ("counter", C.c_void_p),
+        ("bytes", C.c_uint64), ("max_spins", C.c_uint64),
+        ("n_dsts", C.c_int32), ("n_peers", C.c_int32), ("world", C.c_int32), ("my_rank", C.c_int32),
+    ]
+
+
 # every symbol include/dockauv.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("dockauv_abi_version", C.c_int, []),
@@ -96,6 +109,16 @@ SYMBOLS = [
     ("dockauv_step_host", C.c_int, [C.c_void_p, C.POINTER(StepIO)]),
     ("dockauv_synchronize", C.c_int, [C.c_void_p]),
     ("dockauv_time_steps", C.c_int, [C.c_void_p, C.POINTER(StepIO), C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    ("dockauv_p2p_alloc", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.c_char_p]),
+    ("dockauv_p2p_free", C.c_int, [C.c_void_p]),
+    ("dockauv_p2p_open", C.c_int, [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
+    ("dockauv_p2p_close", C.c_int, [C.c_void_p]),
+    ("dockauv_p2p_push", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    ("dockauv_p2p_signal_wait", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint32,
+                                          C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]),
+    ("dockauv_p2p_gather", C.c_int, [C.POINTER(P2PPlan), C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    ("dockauv_step_gather_sequence", C.c_int, [C.c_void_p, C.POINTER(StepIO), C.c_int, C.POINTER(P2PPlan), C.c_int,
+                                               C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]),
 ]
 
 _lib: Optional[C.CDLL] = None

@@ -12,11 +12,14 @@
 #include "../../include/dockauv.h"
 #include "dockauv_device.h"
 
+namespace dockauv {
+thread_local std::string g_create_error;   // dockauv_last_error(NULL); shared with dockauv_p2p.hip
+// dockauv_p2p.hip
+int launch_gather(const dockauv_p2p_plan* pl, const void* src, uint32_t stamp, uint32_t wait_stamp, hipStream_t stream);
+}
 using namespace dockauv;
 
 namespace {
-
-thread_local std::string g_create_error;
 
 struct FieldDesc {
     void* base;   // device base of row 0
@@ -64,6 +67,8 @@ struct dockauv_env_s {
     } pin;
     std::vector<void*> pinned_allocs;
     hipStream_t host_stream = nullptr;
+    hipEvent_t ev_step[2] = {nullptr, nullptr};     // dockauv_step_gather_sequence: step kernel / gather of row buffer k
+    hipEvent_t ev_gather[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -481,6 +486,10 @@ int dockauv_destroy(dockauv_handle h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (void* p : h->pinned_allocs) (void)hipHostFree(p);
     if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
+    for (int k = 0; k < 2; ++k) {
+        if (h->ev_step[k]) (void)hipEventDestroy(h->ev_step[k]);
+        if (h->ev_gather[k]) (void)hipEventDestroy(h->ev_gather[k]);
+    }
     delete h;
     return 0;
 }
@@ -589,6 +598,42 @@ int dockauv_step_sequence(dockauv_handle h, const dockauv_step_io* ios, int n, v
         int rc = launch(h, &ios[i], (hipStream_t)hip_stream);
         if (rc) return rc;
     }
+    return 0;
+}
+
+int dockauv_step_gather_sequence(dockauv_handle h, const dockauv_step_io* ios, int n, const dockauv_p2p_plan* plans,
+                                 int n_plans, uint64_t t0, int lag, void* compute_stream, void* gather_stream) {
+    if (!h || !ios || !plans || n < 0 || n_plans < 1 || lag < 0 || lag > 1) return fail(h, DOCKAUV_E_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i)
+        if (!ios[i].actions || !ios[i].obs || !ios[i].pack_reward_done)
+            return fail(h, DOCKAUV_E_INVALID, "step %d: actions/obs must not be NULL and pack_reward_done must be set", i);
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t cs = (hipStream_t)compute_stream, gs = (hipStream_t)gather_stream;
+    const bool two = cs != gs;
+    if (two)
+        for (int k = 0; k < 2; ++k) {
+            if (!h->ev_step[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_step[k], hipEventDisableTiming));
+            if (!h->ev_gather[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_gather[k], hipEventDisableTiming));
+        }
+    for (int i = 0; i < n; ++i) {
+        const uint64_t t = t0 + (uint64_t)i;
+        const int k = (int)(t & 1);
+        if (two && i >= 2) HIP_TRY(h, hipStreamWaitEvent(cs, h->ev_gather[k], 0));   // rows k are free again
+        int rc = launch(h, &ios[i], cs);
+        if (rc) return rc;
+        if (two) {
+            HIP_TRY(h, hipEventRecord(h->ev_step[k], cs));
+            HIP_TRY(h, hipStreamWaitEvent(gs, h->ev_step[k], 0));
+        }
+        uint32_t stamp = (uint32_t)(t + 1), wait = t + 1 > (uint64_t)lag ? (uint32_t)(t + 1 - (uint64_t)lag) : 0;
+        if (stamp == 0) stamp = 1;
+        rc = launch_gather(&plans[t % (uint64_t)n_plans], ios[i].obs, stamp, wait, gs);
+        if (rc) return fail(h, rc, "%s", g_create_error.c_str());
+        if (two) HIP_TRY(h, hipEventRecord(h->ev_gather[k], gs));
+    }
+    if (two)
+        for (int i = (n >= 2 ? n - 2 : 0); i < n; ++i)
+            HIP_TRY(h, hipStreamWaitEvent(cs, h->ev_gather[(t0 + (uint64_t)i) & 1], 0));
     return 0;
 }
 

@@ -17,6 +17,7 @@
 #ifndef DOCKAUV_H
 #define DOCKAUV_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -206,6 +207,67 @@ int dockauv_synchronize(dockauv_handle h);
  * dispatch carrying its own start/stop HIP events ON THAT STREAM; returns the average KERNEL duration in microseconds
  * (launch gaps excluded -- comparable with rocprofv3 --kernel-trace). */
 int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_stream, int steps, double* avg_us);
+
+/*
+ * Multi-GPU: peer-to-peer gather of the packed [obs | reward | done] rows over xGMI ("keep the
+ * collective pluggable"; the default transport is one RCCL all-gather issued by the host through torch.distributed,
+ * gym_dockauv_amd/parallel.py).  The reference is single-process and has no counterpart; these entry points replace
+ * the concatenation of per-env observations a vectorised caller does on the host (train.py:64-71 consumes it).
+ * One process per GPU.  Every rank owns a gather buffer and a flag array, exports them as IPC handles (the host
+ * exchanges the 64-byte handles over any channel it has), opens its peers' handles, and per step
+ *   1. dockauv_p2p_push: copies its rows into its slice of every rank's gather buffer (one kernel, plain 16-B stores
+ *      over the fabric, system-scope release at the end);
+ *   2. dockauv_p2p_signal_wait: raises stamp t in every peer's flag array and waits -- bounded -- until every peer's
+ *      stamp has reached `wait_stamp` in its own.
+ * All calls are asynchronous on `hip_stream`.  A wait that runs out of `max_spins` sets bit r (r = late rank) in
+ * status[0] and stores the stamp in status[1]; every later wait then returns at once (the grid always drains).
+ */
+#define DOCKAUV_P2P_HANDLE_BYTES 64
+#define DOCKAUV_P2P_MAX_PEERS 15
+/* device memory a peer process can map; uncached != 0: fine-grained (what a peer stores is seen by a kernel that is
+ * already running: required for flag arrays; far too slow for gather buffers, which are read by later kernels only).
+ * `handle` (nullable) receives DOCKAUV_P2P_HANDLE_BYTES bytes. */
+int dockauv_p2p_alloc(int device, size_t bytes, int uncached, void** dev_ptr, unsigned char* handle);
+int dockauv_p2p_free(void* dev_ptr);
+/* map / unmap a peer's allocation on `device` */
+int dockauv_p2p_open(int device, const unsigned char* handle, void** dev_ptr);
+int dockauv_p2p_close(void* dev_ptr);
+/* copy `bytes` from src (16-byte aligned) to each of dsts[0..n_dsts) (local or peer-mapped, 16-byte aligned) */
+int dockauv_p2p_push(const void* src, size_t bytes, void* const* dsts, int n_dsts, void* hip_stream);
+/* peer_slots[p] = &flags_of_peer_p[my_rank]; my_flags = this rank's flag array [world]; status = uint32 [2] in device
+ * memory of this rank; stamp / wait_stamp: 0 = skip that half; stamps compare modulo 2^32 */
+int dockauv_p2p_signal_wait(uint32_t* const* peer_slots, int n_peers, const uint32_t* my_flags, int world, int my_rank,
+                            uint32_t stamp, uint32_t wait_stamp, uint64_t max_spins, uint32_t* status,
+                            void* hip_stream);
+
+/*
+ * The same gather as ONE kernel: the blocks copy; the block that finishes last (device counter) raises `stamp` at the
+ * peers and waits for `wait_stamp`.  A plan is a plain description of one rank's view of one gather buffer.
+ */
+typedef struct dockauv_p2p_plan {
+    void* dsts[DOCKAUV_P2P_MAX_PEERS + 1];        /* this rank's slice in every rank's gather buffer (own included) */
+    uint32_t* peer_slots[DOCKAUV_P2P_MAX_PEERS];  /* &flags_of_peer_p[my_rank] */
+    const uint32_t* my_flags;                     /* [world], written by the peers */
+    uint32_t* status;                             /* [2], this rank */
+    uint32_t* counter;                            /* [1], this rank, zero between gathers */
+    uint64_t bytes;                               /* size of the slice */
+    uint64_t max_spins;
+    int32_t n_dsts, n_peers, world, my_rank;
+} dockauv_p2p_plan;
+int dockauv_p2p_gather(const dockauv_p2p_plan* plan, const void* src, uint32_t stamp, uint32_t wait_stamp,
+                       void* hip_stream);
+/*
+ * n steps with their gathers, queued by one host call: step i (global step number t0 + i) writes its packed rows to
+ * ios[i].obs, which must be row buffer (t0 + i) % 2 of the caller's two; its gather follows with plan
+ * (t0 + i) % n_plans, raising stamp t0 + i + 1 and waiting for stamp t0 + i + 1 - lag (lag 0 or 1; with lag 1 the last
+ * gather's stamps are still awaited afterwards -- dockauv_p2p_signal_wait with stamp 0).
+ * gather_stream == compute_stream: everything in order on one stream (cheapest for microsecond kernels).
+ * gather_stream != compute_stream: the transfer of step t runs beside the kernel of step t + 1; the step kernel that next
+ * writes the same row buffer waits for that gather, and on return (asynchronous) `compute_stream` is ordered after
+ * every gather queued here.  Costs five stream/event calls per step on the host: for transfers much longer than that.
+ */
+int dockauv_step_gather_sequence(dockauv_handle h, const dockauv_step_io* ios, int n, const dockauv_p2p_plan* plans,
+                                 int n_plans, uint64_t t0, int lag, void* compute_stream, void* gather_stream);
 
 #ifdef __cplusplus
 }

@@ -47,16 +47,18 @@ def test_struct_layout_matches_c(tmp_path):
 #include <stddef.h>
 #include "{HEADER}"
 int main(void) {{
-  printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dockauv_config), sizeof(dockauv_vehicle), sizeof(dockauv_step_io),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(dockauv_config), sizeof(dockauv_vehicle), sizeof(dockauv_step_io),
          offsetof(dockauv_config, seed), offsetof(dockauv_config, ray_table), offsetof(dockauv_config, vehicle),
-         offsetof(dockauv_vehicle, lauv));
+         offsetof(dockauv_vehicle, lauv), sizeof(dockauv_p2p_plan), offsetof(dockauv_p2p_plan, my_flags),
+         offsetof(dockauv_p2p_plan, n_dsts));
   return 0;
 }}''')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c99", "-o", str(exe), str(src)])
     out = subprocess.check_output([str(exe)]).decode().split()
     got = [C.sizeof(_capi.Config), C.sizeof(_capi.Vehicle), C.sizeof(_capi.StepIO), _capi.Config.seed.offset,
-           _capi.Config.ray_table.offset, _capi.Config.vehicle.offset, _capi.Vehicle.lauv.offset]
+           _capi.Config.ray_table.offset, _capi.Config.vehicle.offset, _capi.Vehicle.lauv.offset,
+           C.sizeof(_capi.P2PPlan), _capi.P2PPlan.my_flags.offset, _capi.P2PPlan.n_dsts.offset]
     assert [int(x) for x in out] == got
 
 

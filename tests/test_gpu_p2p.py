@@ -1,0 +1,82 @@
+"""Peer-to-peer gather (include/dockauv.h "Multi-GPU" block, gym_dockauv_amd/parallel.py: P2PGather) on the GPU:
+a single rank, and a rehearsal with two and three rank PROCESSES sharing the box's one GPU (IPC handles, push kernel,
+stamps and bounded waits are what runs across GPUs; only the fabric is missing)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_single_rank_push_and_timeout():
+    import torch
+    from gym_dockauv_amd.parallel import P2PGather
+    dev = torch.device("cuda", 0)
+    n_local, row = 100, 12
+    g = P2PGather(n_local, row, 0, world=1, rank=0, lag=0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for t in range(5):
+        rows = torch.randn((n_local, row), device=dev)
+        buf = g.push(rows.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, rows)
+        assert buf.data_ptr() == g.buffer(t % 2).data_ptr()
+    assert g.timed_out() == 0
+    g.close()
+    with pytest.raises(ValueError):
+        P2PGather(3, 5, 0, world=1, rank=0)          # 60-byte slices
+
+
+def test_wait_is_bounded_when_a_peer_never_signals():
+    """A rank of a 2-rank world whose peer never shows up: the wait runs out of spins, sets the peer's bit, and every
+    later wait returns at once (the C entry points directly; the peer's flag array is stood in for by local memory)."""
+    import ctypes as C
+    import torch
+    from gym_dockauv_amd import _capi
+    lib = _capi.load_library()
+    flags, other = C.c_void_p(), C.c_void_p()
+    assert lib.dockauv_p2p_alloc(0, 256, 1, C.byref(flags), None) == 0
+    assert lib.dockauv_p2p_alloc(0, 256, 1, C.byref(other), None) == 0
+    slots = (C.c_void_p * 1)(other.value + 0)        # "peer 1's flags[0]"
+    stream = torch.cuda.current_stream().cuda_stream
+    status = flags.value + 128
+    for stamp in (1, 2, 3):
+        assert lib.dockauv_p2p_signal_wait(slots, 1, flags.value, 2, 0, stamp, stamp, 2000, status, stream) == 0
+    torch.cuda.synchronize()
+    from gym_dockauv_amd.parallel import _DevArray
+    st = torch.as_tensor(_DevArray(status, (2,), "<i4"), device="cuda:0").cpu().numpy()
+    ot = torch.as_tensor(_DevArray(other.value, (1,), "<i4"), device="cuda:0").cpu().numpy()
+    assert st[0] == 0b10 and st[1] == 1              # rank 1 was late, first at stamp 1
+    assert ot[0] == 3                                # our stamps still went out
+    assert lib.dockauv_p2p_free(flags) == 0 and lib.dockauv_p2p_free(other) == 0
+    assert lib.dockauv_p2p_signal_wait(slots, 99, flags.value, 2, 0, 1, 1, 10, status, stream) == _capi_invalid()
+
+
+def _capi_invalid():
+    return -1
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rank_processes_on_one_gpu_gather_bit_exact(world):
+    port = 29700 + (os.getpid() % 200) + world
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.p2p_worker", str(r), str(world), str(port), "640", "12"],
+                              cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+        assert "0 bad" in out
+        print("".join(l + "\n" for l in out.splitlines() if " us " in l), end="")    # pace lines (pytest -s)
