@@ -110,7 +110,7 @@ class P2PGather:
     """
 
     def __init__(self, n_local: int, row_len: int, device_index: int, world: int, rank: int, group=None, lag: int = 0,
-                 n_buffers: Optional[int] = None, uncached: bool = False, max_spins: int = 4_000_000):
+                 n_buffers: Optional[int] = None, uncached: bool = False, max_spins: int = 8_000_000):
         import ctypes as C
         import torch
         import torch.distributed as dist
