@@ -189,7 +189,7 @@ def main():
     stepper.use_dist = use_dist
     rccl_stepper = stepper
     transport, p2p_note, n_verify = ("rccl" if use_dist else "none"), None, 0
-    two_streams = N * (n_obs + 2) * 4 >= (2 << 20)      # P2PShardedStepper.run_sequence's own rule
+    two_streams = False     # gathers on a second stream: measured slower on one GPU at every size (parallel.py)
     if use_dist and args.gather in ("auto", "p2p"):
         # peer-to-peer transport: accepted only if every rank mapped its peers AND the gathered rows of the first
         # warm-up steps equal an RCCL all-gather of the same rows bit for bit on every rank
