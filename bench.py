@@ -209,6 +209,18 @@ def main():
                 p2p.wait()
                 dist.all_gather_into_tensor(ref, p2p.rows)
                 ok &= int(torch.equal(buf.view(torch.int32), ref.view(torch.int32)))
+            if not args.no_overlap:
+                # the timed region's form: one-call sequences whose gathers ride in the next step kernel; the last two
+                # steps' rows are still at hand afterwards, so the ridden gather and the closing one are both compared
+                for rep in range(2):
+                    i0 = n_verify
+                    seq = p2p.make_sequence(env, [actions[i % RING].data_ptr() for i in range(i0, i0 + 5)])
+                    p2p.run_sequence(env, seq)
+                    n_verify += 5
+                    t_last = p2p.gather.t - 1
+                    for back in (0, 1):
+                        dist.all_gather_into_tensor(ref, p2p.rows2[(t_last - back) & 1])
+                        ok &= int(torch.equal(p2p.bufs[(t_last - back) % p2p.gather.nb].view(torch.int32), ref.view(torch.int32)))
             ok &= int(p2p.gather.timed_out() == 0)
             flag = torch.tensor([ok], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -322,12 +334,13 @@ def main():
                       + ("" if args.no_overlap else ", overlapped with the next step's kernel"))
     else:
         collective = ("peer-to-peer push of packed [obs|reward|done] into every rank's gather buffer + step stamps "
-                      "(dockauv_p2p_*): one copy kernel per step, every rank holds all rows of step t "
+                      "(dockauv_p2p_*), every rank holds all rows of step t "
                       + ("before step t + 1 starts, issued step by step" if args.no_overlap else
-                         "two steps later at the latest (copy on a second stream beside the next step kernel), one host "
-                         "call per region" if two_streams else
-                         "before step t + 1 starts (same stream as the step kernel), one host call per region")
-                      + f"; checked bit-exact against an rccl all_gather on the first {n_verify} warm-up steps")
+                         "when its step kernel t + 1 has ended: the copy groups of step t ride in the grid of step kernel "
+                         "t + 1 (transfer beside the arithmetic, one launch per step, one host call per region)"
+                         if stepper._ride_ok else
+                         "before step t + 1 starts (gather kernel after each step kernel, one host call per region)")
+                      + f"; checked bit-exact against an rccl all_gather during the first {n_verify} warm-up steps")
     if rank == 0:
         bytes_per_launch = ALGO_BYTES[args.config] * N
         achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9

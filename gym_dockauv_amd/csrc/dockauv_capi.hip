@@ -67,6 +67,8 @@ struct dockauv_env_s {
     } pin;
     std::vector<void*> pinned_allocs;
     hipStream_t host_stream = nullptr;
+    void* ride_plans_dev = nullptr;                 // device copies of the caller's gather plans (lag-1 sequences)
+    std::vector<unsigned char> ride_plans_host;
     hipEvent_t ev_step[2] = {nullptr, nullptr};     // dockauv_step_gather_sequence: step kernel / gather of row buffer k
     hipEvent_t ev_gather[2] = {nullptr, nullptr};
 };
@@ -486,6 +488,7 @@ int dockauv_destroy(dockauv_handle h) {
     for (void* p : h->allocs) (void)hipFree(p);
     for (void* p : h->pinned_allocs) (void)hipHostFree(p);
     if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
+    if (h->ride_plans_dev) (void)hipFree(h->ride_plans_dev);
     for (int k = 0; k < 2; ++k) {
         if (h->ev_step[k]) (void)hipEventDestroy(h->ev_step[k]);
         if (h->ev_gather[k]) (void)hipEventDestroy(h->ev_gather[k]);
@@ -610,6 +613,58 @@ int dockauv_step_gather_sequence(dockauv_handle h, const dockauv_step_io* ios, i
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t cs = (hipStream_t)compute_stream, gs = (hipStream_t)gather_stream;
     const bool two = cs != gs;
+    if (!two && lag == 1) {
+        // the gather of step t rides in the grid of step kernel t + 1 (dockauv_ride.h); the last one is flushed by a
+        // gather kernel of its own, so that on return everything queued here is covered by the stream
+        if (h->f64 || !h->sym) return fail(h, DOCKAUV_E_INVALID, "lag 1 needs the float kernels of the structural fast path");
+        for (int k = 0; k < n_plans; ++k)
+            if (plans[k].bytes == 0 || plans[k].bytes % 16 != 0 || !plans[k].counter || !plans[k].status || !plans[k].my_flags ||
+                plans[k].n_dsts < 1 || plans[k].n_dsts > DOCKAUV_P2P_MAX_PEERS + 1 || plans[k].n_peers < 0 ||
+                plans[k].n_peers > DOCKAUV_P2P_MAX_PEERS)
+                return fail(h, DOCKAUV_E_INVALID, "plan %d: bad plan (slices must be multiples of 16 bytes)", k);
+        const size_t pbytes = sizeof(dockauv_p2p_plan) * (size_t)n_plans;
+        if (h->ride_plans_host.size() != pbytes || memcmp(h->ride_plans_host.data(), plans, pbytes) != 0) {
+            if (h->ride_plans_host.size() != pbytes) {
+                if (h->ride_plans_dev) {
+                    HIP_TRY(h, hipStreamSynchronize(cs));
+                    HIP_TRY(h, hipFree(h->ride_plans_dev));
+                    h->ride_plans_dev = nullptr;
+                }
+                HIP_TRY(h, hipMalloc(&h->ride_plans_dev, pbytes));
+            } else {
+                HIP_TRY(h, hipStreamSynchronize(cs));
+            }
+            HIP_TRY(h, hipMemcpy(h->ride_plans_dev, plans, pbytes, hipMemcpyHostToDevice));
+            h->ride_plans_host.assign(reinterpret_cast<const unsigned char*>(plans), reinterpret_cast<const unsigned char*>(plans) + pbytes);
+        }
+        const unsigned long n16 = plans[0].bytes / 16;
+        unsigned long cg = n16 / ((unsigned long)h->threads * 2);
+        cg = cg < 8 ? 8 : (cg > 256 ? 256 : cg);
+        RideLaunch& ride = h->a32.ride;
+        for (int i = 0; i < n; ++i) {
+            const uint64_t t = t0 + (uint64_t)i;
+            ride = RideLaunch{};
+            if (i >= 1) {
+                uint32_t stamp = (uint32_t)t;            // gather of step t - 1 carries stamp (t - 1) + 1
+                if (stamp == 0) stamp = 1;
+                ride.plan = static_cast<const dockauv_p2p_plan*>(h->ride_plans_dev) + ((t - 1) % (uint64_t)n_plans);
+                ride.src = ios[i - 1].obs;
+                ride.stamp = ride.wait_stamp = stamp;
+                ride.groups = (int)cg;
+            }
+            int rc = launch(h, &ios[i], cs);
+            ride = RideLaunch{};
+            if (rc) return rc;
+        }
+        if (n >= 1) {
+            const uint64_t t = t0 + (uint64_t)(n - 1);
+            uint32_t stamp = (uint32_t)(t + 1);
+            if (stamp == 0) stamp = 1;
+            int rc = launch_gather(&plans[t % (uint64_t)n_plans], ios[n - 1].obs, stamp, stamp, cs);
+            if (rc) return fail(h, rc, "%s", g_create_error.c_str());
+        }
+        return 0;
+    }
     if (two)
         for (int k = 0; k < 2; ++k) {
             if (!h->ev_step[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_step[k], hipEventDisableTiming));

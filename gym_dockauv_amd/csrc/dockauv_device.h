@@ -109,6 +109,14 @@ struct ParamBlock {
     VehicleP<T> V[NV];
 };
 
+// copy groups riding in the launch (dockauv_ride.h); plan == nullptr: none
+struct RideLaunch {
+    const void* plan = nullptr;   // dockauv_p2p_plan in DEVICE memory
+    const void* src = nullptr;    // previous step's rows
+    uint32_t stamp = 0, wait_stamp = 0;
+    int groups = 0;               // copy groups appended to the grid
+};
+
 // host-side bundle of everything a launch needs
 template <typename T, int NV>
 struct KernelArgs {
@@ -116,6 +124,7 @@ struct KernelArgs {
     const void* params_dev;   // device copy of P
     Buffers B;
     StepIO io;
+    RideLaunch ride;
 };
 
 // what actually travels in the kernarg segment (29 pointers + 2 ints)

@@ -41,7 +41,7 @@ struct PushArgs {
     const uint4* src;
     unsigned long n16;      // whole 16-byte chunks
     unsigned long bytes;    // total (tail bytes copied by the first lanes of block 0)
-    uint4* dst[DOCKAUV_P2P_MAX_PEERS];
+    uint4* dst[DOCKAUV_P2P_MAX_PEERS + 1];   // own slice included
 };
 
 // Rows are copied with SYSTEM-SCOPE (write-through, `sc0 sc1`) 16-byte stores: such a store is acknowledged only once
@@ -254,7 +254,7 @@ int dockauv_p2p_close(void* dev_ptr) {
 
 int dockauv_p2p_push(const void* src, size_t bytes, void* const* dsts, int n_dsts, void* hip_stream) {
     if (n_dsts == 0 || bytes == 0) return DOCKAUV_OK;
-    if (!src || !dsts || n_dsts < 0 || n_dsts > DOCKAUV_P2P_MAX_PEERS) return p2p_invalid("dockauv_p2p_push: bad argument");
+    if (!src || !dsts || n_dsts < 0 || n_dsts > DOCKAUV_P2P_MAX_PEERS + 1) return p2p_invalid("dockauv_p2p_push: bad argument");
     if ((reinterpret_cast<uintptr_t>(src) & 15) != 0) return p2p_invalid("dockauv_p2p_push: src must be 16-byte aligned");
     PushArgs a{};
     a.src = static_cast<const uint4*>(src);

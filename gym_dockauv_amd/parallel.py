@@ -296,24 +296,27 @@ class P2PGather:
 
 
 class P2PShardedStepper:
-    """ShardedStepper with the P2PGather transport.  `step` = step kernel -> rows -> one gather kernel, on the current
-    stream (closed loop, or lag 1 with `overlap`).  `run_sequence` = n open-loop steps queued by one host call
-    (dockauv_step_gather_sequence) on two streams, the transfer of step t beside the kernel of step t + 1."""
+    """ShardedStepper with the P2PGather transport.  `step` = step kernel -> rows -> one gather kernel on the current
+    stream (closed loop; `lag=1`: the wait covers the previous step).  `run_sequence` = n open-loop steps queued by one
+    host call (dockauv_step_gather_sequence); with `overlap` the gather of step t rides in the grid of step kernel
+    t + 1."""
 
     def __init__(self, n_local: int, row_len: int, step_fn: Callable, device, world: int = 1, rank: int = 0,
-                 group=None, overlap: bool = True, fused: bool = True, **kw):
+                 group=None, overlap: bool = True, fused: bool = True, lag: int = 0, **kw):
         import torch
         self.torch = torch
         self.n_local, self.row_len, self.world, self.rank = int(n_local), int(row_len), int(world), int(rank)
         self.step_fn = step_fn
         self.device = torch.device(device)
         self.fused = bool(fused)
+        self.overlap = bool(overlap)          # run_sequence: gathers ride in the next step kernel
         self.gather = P2PGather(n_local, row_len, self.device.index or 0, world, rank, group=group,
-                                lag=1 if overlap else 0, n_buffers=4, **kw)
+                                lag=lag, n_buffers=4, **kw)
         self.rows2 = [torch.zeros((n_local, row_len), device=self.device, dtype=torch.float32) for _ in range(2)]
         self.rows = self.rows2[0]             # rows of the last step
         self.bufs = [self.gather.buffer(k) for k in range(self.gather.nb)]
         self._gather_stream = None
+        self._ride_ok = True
 
     def local_slice(self, buf):
         return buf[self.rank * self.n_local:(self.rank + 1) * self.n_local]
@@ -339,7 +342,7 @@ class P2PShardedStepper:
             ios[i].pack_reward_done = 1
         return (ios, len(action_ptrs), t0 & 1)
 
-    def run_sequence(self, env, seq, two_streams: Optional[bool] = None) -> None:
+    def run_sequence(self, env, seq, two_streams: Optional[bool] = None, ride: Optional[bool] = None) -> None:
         """two_streams: gathers on a second stream beside the next step kernel.  Off by default: the two cross-stream
         dependencies per step cost more than they hide at every size measured on one GPU (4 096 envs: 17.4 vs 9.5 us
         per step; 32 768 envs with an 18 us local copy: 31 vs 24.5 us); it can only pay where the fabric transfer is
@@ -355,9 +358,19 @@ class P2PShardedStepper:
             if self._gather_stream is None:
                 self._gather_stream = self.torch.cuda.Stream(device=self.device)
             gs = self._gather_stream.cuda_stream
-        # every gather waits for its own step's stamps (lag 0): all ranks hold step t before any starts step t + 1
-        # on one stream; on two streams the wait sits on the gather stream, beside the next step kernel
-        rc = g.lib.dockauv_step_gather_sequence(env._handle, ios, n, g._plans, g.nb, g.t, 0, cs, gs)
+        # ride (one stream): the gather of step t travels in the grid of step kernel t + 1, its transfer hidden behind
+        # that step's arithmetic; every rank holds all rows of step t once ITS kernel t + 1 has ended (the last step
+        # of the region: once the closing gather kernel has).  Without ride every gather is a kernel of its own that
+        # awaits its step's stamps before the next step kernel starts.
+        if ride is None:
+            ride = self.overlap
+        lag = 1 if (ride and not two_streams and self._ride_ok) else 0
+        rc = g.lib.dockauv_step_gather_sequence(env._handle, ios, n, g._plans, g.nb, g.t, lag, cs, gs)
+        if rc != 0 and lag == 1:
+            msg = g.lib.dockauv_last_error(env._handle)
+            if msg and b"lag 1 needs" in msg:       # float64 / general-expression kernels have no ride variant
+                self._ride_ok = False
+                rc = g.lib.dockauv_step_gather_sequence(env._handle, ios, n, g._plans, g.nb, g.t, 0, cs, gs)
         if rc != 0:
             msg = g.lib.dockauv_last_error(env._handle)
             raise g._capi.DockAUVError(f"dockauv_step_gather_sequence failed ({rc}): {msg.decode() if msg else '?'}")

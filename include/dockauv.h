@@ -258,13 +258,18 @@ int dockauv_p2p_gather(const dockauv_p2p_plan* plan, const void* src, uint32_t s
                        void* hip_stream);
 /*
  * n steps with their gathers, queued by one host call: step i (global step number t0 + i) writes its packed rows to
- * ios[i].obs, which must be row buffer (t0 + i) % 2 of the caller's two; its gather follows with plan
- * (t0 + i) % n_plans, raising stamp t0 + i + 1 and waiting for stamp t0 + i + 1 - lag (lag 0 or 1; with lag 1 the last
- * gather's stamps are still awaited afterwards -- dockauv_p2p_signal_wait with stamp 0).
- * gather_stream == compute_stream: everything in order on one stream (cheapest for microsecond kernels).
- * gather_stream != compute_stream: the transfer of step t runs beside the kernel of step t + 1; the step kernel that next
- * writes the same row buffer waits for that gather, and on return (asynchronous) `compute_stream` is ordered after
- * every gather queued here.  Costs five stream/event calls per step on the host: for transfers much longer than that.
+ * ios[i].obs, which must be row buffer (t0 + i) % 2 of the caller's two; its gather uses plan (t0 + i) % n_plans and
+ * stamp t0 + i + 1 (raised at the peers and awaited from them).  On return (asynchronous) `compute_stream` is ordered
+ * after every gather queued here.
+ * gather_stream == compute_stream, lag 0: step kernel, gather kernel, step kernel, ... in order: every rank holds all
+ *   rows of step t before step t + 1 starts.
+ * gather_stream == compute_stream, lag 1: the gather of step t RIDES in the grid of step kernel t + 1 (extra workgroups
+ *   behind the step groups push the previous rows while the step groups integrate: the fabric transfer is hidden
+ *   behind the arithmetic, one launch per step); the last gather gets a kernel of its own.  Needs >= 4 plans, float
+ *   kernels, slices that are multiples of 16 bytes.
+ * gather_stream != compute_stream (lag ignored): gather kernels on a second stream beside the next step kernel; the step
+ *   kernel that next writes the same row buffer waits for that gather.  Five stream/event calls per step on the host
+ *   and two cross-stream dependencies: measured slower than one stream at every size on one GPU.
  */
 int dockauv_step_gather_sequence(dockauv_handle h, const dockauv_step_io* ios, int n, const dockauv_p2p_plan* plans,
                                  int n_plans, uint64_t t0, int lag, void* compute_stream, void* gather_stream);

@@ -36,17 +36,17 @@ for overlap in (False, True):
     torch.cuda.synchronize()
     base = (time.perf_counter() - t0) / K * 1e6
     res = {}
-    for two in (False, True):
+    for two in (False, True, "ride"):
         seq = st.make_sequence(env, [actions[i % 64].data_ptr() for i in range(K)])
-        st.run_sequence(env, seq, two_streams=two)
+        st.run_sequence(env, seq, two_streams=two is True, ride=two == "ride")
         st.wait()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        st.run_sequence(env, seq, two_streams=two)
+        st.run_sequence(env, seq, two_streams=two is True, ride=two == "ride")
         st.wait()
         torch.cuda.synchronize()
         res[two] = (time.perf_counter() - t0) / K * 1e6
     print(f"{N} envs, lag {int(overlap)}: step kernel alone {base:.2f} us/step; + gather kernel, one stream {res[False]:.2f}; "
-          f"two streams {res[True]:.2f}", flush=True)
+          f"two streams {res[True]:.2f}; gathers riding in the next step kernel {res['ride']:.2f}", flush=True)
     st.close()
 env.close()

@@ -36,10 +36,10 @@ def main() -> int:
         actions = torch.rand((steps, world, n_local, n_u), device=dev, generator=gen) * 2 - 1   # same on every rank
         mirror = torch.zeros((world, n_local, row), device=dev)
         bad = 0
-        for overlap, fused in ((False, True), (True, True), (False, False), (True, False)):
+        for overlap, fused in ((False, True), (True, True), (False, False), (True, False)):     # overlap = lag 1 here
             def step_fn(a, out):
                 envs[rank].step_device(a.data_ptr(), out.data_ptr(), stream=stream, packed=True)
-            st = P2PShardedStepper(n_local, row, step_fn, dev, world=world, rank=rank, overlap=overlap, fused=fused)
+            st = P2PShardedStepper(n_local, row, step_fn, dev, world=world, rank=rank, lag=1 if overlap else 0, fused=fused)
             expected = []
             got = []
             for t in range(steps):
@@ -64,10 +64,10 @@ def main() -> int:
                     print(f"rank {rank} overlap {overlap} step {t}: gathered rows differ", flush=True)
             # open-loop sequences (one host call each), on one stream and on two: afterwards every buffer of the
             # rotation holds the gathered rows of its step
-            for two in (False, True):
+            for two, ride in ((False, True), (False, False), (True, False)):
                 seq = st.make_sequence(envs[rank], [actions[t, rank].data_ptr() for t in range(steps)])
                 t_first = st.gather.t
-                st.run_sequence(envs[rank], seq, two_streams=two)
+                st.run_sequence(envs[rank], seq, two_streams=two, ride=ride)
                 st.wait()
                 exp_seq = []
                 for t in range(steps):
@@ -81,10 +81,13 @@ def main() -> int:
                     for r in range(world):
                         if r != rank and not torch.equal(buf[r].view(torch.int32), exp_seq[t][r].view(torch.int32)):
                             bad += 1
-                            print(f"rank {rank} sequence (two streams: {two}) step {t}: rows of rank {r} differ", flush=True)
+                            print(f"rank {rank} sequence (two streams: {two}, ride: {ride}) step {t}: rows of rank {r} differ", flush=True)
                 if not torch.equal(st.local_slice(st.bufs[(t_first + steps - 1) % st.gather.nb]), st.rows):
                     bad += 1
-                    print(f"rank {rank} sequence (two streams: {two}): own rows differ", flush=True)
+                    print(f"rank {rank} sequence (two streams: {two}, ride: {ride}): own rows differ", flush=True)
+                # the buffers were read from the HOST, four steps late: no rank may go on (and reuse them) before
+                # every rank has looked (a learner reads step t on the step stream before its step t + 2)
+                dist.barrier()
             # pace of the whole per-step chain (step kernel, push, stamps) with every rank on this one GPU
             torch.cuda.synchronize()
             dist.barrier()
@@ -101,12 +104,12 @@ def main() -> int:
                     if r != rank:
                         envs[r].step_device(actions[t % steps, r].data_ptr(), mirror[r].data_ptr(), stream=stream, packed=True)
             us2 = {}
-            for two in (False, True):
+            for two in (False, True, "ride"):
                 seq = st.make_sequence(envs[rank], [actions[t % steps, rank].data_ptr() for t in range(200)])
                 torch.cuda.synchronize()
                 dist.barrier()
                 t0 = time.perf_counter()
-                st.run_sequence(envs[rank], seq, two_streams=two)
+                st.run_sequence(envs[rank], seq, two_streams=two is True, ride=two == "ride")
                 st.wait()
                 torch.cuda.synchronize()
                 us2[two] = (time.perf_counter() - t0) / 200 * 1e6
@@ -116,7 +119,7 @@ def main() -> int:
                         if r != rank:
                             envs[r].step_device(actions[t % steps, r].data_ptr(), mirror[r].data_ptr(), stream=stream, packed=True)
             print(f"rank {rank} overlap {overlap} fused {fused}: {us:.1f} us per step+gather from Python; one-call sequence "
-                  f"{us2[False]:.1f} us (one stream), {us2[True]:.1f} us (two streams) ({world} ranks on one GPU, {n_local} envs each)", flush=True)
+                  f"{us2['ride']:.1f} us (gathers riding in the next step kernel), {us2[False]:.1f} us (gather kernels, one stream), {us2[True]:.1f} us (two streams) ({world} ranks on one GPU, {n_local} envs each)", flush=True)
             dist.barrier()
             st.close()
         for e in envs:
