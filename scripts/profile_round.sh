@@ -27,6 +27,14 @@ prof config2 --config 2
 prof config2_1M --config 2 --envs 1048576 --steps 200 --warmup 20
 prof config3 --config 3 --steps 300 --warmup 30
 prof config4 --config 4 --steps 300 --warmup 30
+# --- the multi-GPU step with ONE rank (no fabric): step kernels with riding copy groups (dockauv::step_ride_kernel)
+(
+  export WORLD_SIZE=1 RANK=0 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 DOCKAUV_FORCE_DIST=1
+  OUT=$ROOT/p2p_one_rank; mkdir -p $OUT
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu --no-sweep --gather p2p > $OUT/bench_line.json 2> $OUT/bench_trace.err || tail -5 $OUT/bench_trace.err
+  find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
+  echo "== p2p_one_rank"; head -6 $OUT/kernel_stats.csv
+)
 python3 - $ROOT <<'PY'
 import json, os, sys
 root = sys.argv[1]
