@@ -159,7 +159,11 @@ def main():
         os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("DOCKAUV_DIST_BACKEND", "nccl") == "gloo":
+            # rehearsal only (scripts/bench_ranks_one_gpu.sh): several ranks on ONE GPU, which RCCL refuses
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
 
     from gym_dockauv_amd.envs.batched import BatchedDocking3d
     wl = workload(args.config, args.envs)

@@ -617,6 +617,10 @@ int dockauv_step_gather_sequence(dockauv_handle h, const dockauv_step_io* ios, i
         // the gather of step t rides in the grid of step kernel t + 1 (dockauv_ride.h); the last one is flushed by a
         // gather kernel of its own, so that on return everything queued here is covered by the stream
         if (h->f64 || !h->sym) return fail(h, DOCKAUV_E_INVALID, "lag 1 needs the float kernels of the structural fast path");
+        if (n_plans < 4) return fail(h, DOCKAUV_E_INVALID, "lag 1 needs at least 4 plans (gather buffers)");
+        for (int i = 1; i < n; ++i)
+            if (ios[i].obs == ios[i - 1].obs)
+                return fail(h, DOCKAUV_E_INVALID, "step %d: lag 1 needs alternating row buffers (obs of consecutive steps differ)", i);
         for (int k = 0; k < n_plans; ++k)
             if (plans[k].bytes == 0 || plans[k].bytes % 16 != 0 || !plans[k].counter || !plans[k].status || !plans[k].my_flags ||
                 plans[k].n_dsts < 1 || plans[k].n_dsts > DOCKAUV_P2P_MAX_PEERS + 1 || plans[k].n_peers < 0 ||

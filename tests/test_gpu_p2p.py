@@ -80,3 +80,36 @@ def test_rank_processes_on_one_gpu_gather_bit_exact(world):
         assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
         assert "0 bad" in out
         print("".join(l + "\n" for l in out.splitlines() if " us " in l), end="")    # pace lines (pytest -s)
+
+
+def test_sequence_argument_checks():
+    """dockauv_step_gather_sequence refuses what would race: fewer than 4 plans or one row buffer with riding gathers."""
+    import ctypes as C
+    import torch
+    from gym_dockauv_amd import _capi
+    from gym_dockauv_amd.envs.batched import BASE_CONFIG, BatchedDocking3d
+    from gym_dockauv_amd.parallel import P2PShardedStepper
+    dev = torch.device("cuda", 0)
+    env = BatchedDocking3d(BASE_CONFIG, num_envs=128, scenario="SimpleDocking3d", device=0, precision="f32",
+                           reset_mode="device", device_seed=3, rng="batched")
+    env.reset()
+    stream = torch.cuda.current_stream().cuda_stream
+    st = P2PShardedStepper(128, env.n_observations + 2, lambda a, o: None, dev, world=1, rank=0)
+    actions = torch.zeros((128, env.n_u), device=dev)
+    ios = (_capi.StepIO * 3)()
+    for i in range(3):
+        ios[i].actions, ios[i].obs, ios[i].pack_reward_done = actions.data_ptr(), st.rows2[0].data_ptr(), 1
+    lib, g = st.gather.lib, st.gather
+    assert lib.dockauv_step_gather_sequence(env._handle, ios, 3, g._plans, 4, 0, 1, stream, stream) == -1
+    assert b"alternating row buffers" in lib.dockauv_last_error(env._handle)
+    for i in range(3):
+        ios[i].obs = st.rows2[i & 1].data_ptr()
+    assert lib.dockauv_step_gather_sequence(env._handle, ios, 3, g._plans, 2, 0, 1, stream, stream) == -1
+    assert b"at least 4 plans" in lib.dockauv_last_error(env._handle)
+    assert lib.dockauv_step_gather_sequence(env._handle, ios, 3, g._plans, 4, 0, 2, stream, stream) == -1
+    assert lib.dockauv_step_gather_sequence(env._handle, ios, 3, g._plans, 4, 0, 1, stream, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(st.bufs[2], st.rows2[0]) and torch.equal(st.bufs[1], st.rows2[1])
+    assert g.timed_out() == 0
+    st.close()
+    env.close()
