@@ -36,7 +36,9 @@ def main() -> int:
         actions = torch.rand((steps, world, n_local, n_u), device=dev, generator=gen) * 2 - 1   # same on every rank
         mirror = torch.zeros((world, n_local, row), device=dev)
         bad = 0
-        for overlap, fused in ((False, True), (True, True), (False, False), (True, False)):     # overlap = lag 1 here
+        combos = ((False, True), (True, True), (False, False), (True, False))
+        order = [int(k) for k in os.environ.get("P2P_WORKER_ORDER", "0,1,2,3").split(",")]
+        for overlap, fused in [combos[k] for k in order]:     # overlap = lag 1 here
             def step_fn(a, out):
                 envs[rank].step_device(a.data_ptr(), out.data_ptr(), stream=stream, packed=True)
             st = P2PShardedStepper(n_local, row, step_fn, dev, world=world, rank=rank, lag=1 if overlap else 0, fused=fused)
