@@ -215,8 +215,8 @@ int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_st
  * the concatenation of per-env observations a vectorised caller does on the host (train.py:64-71 consumes it).
  * One process per GPU.  Every rank owns a gather buffer and a flag array, exports them as IPC handles (the host
  * exchanges the 64-byte handles over any channel it has), opens its peers' handles, and per step
- *   1. dockauv_p2p_push: copies its rows into its slice of every rank's gather buffer (one kernel, plain 16-B stores
- *      over the fabric, system-scope release at the end);
+ *   1. dockauv_p2p_push: copies its rows into its slice of every rank's gather buffer (one kernel, system-scope
+ *      write-through 16-byte stores over the fabric, each wave waits for its acknowledgements);
  *   2. dockauv_p2p_signal_wait: raises stamp t in every peer's flag array and waits -- bounded -- until every peer's
  *      stamp has reached `wait_stamp` in its own.
  * All calls are asynchronous on `hip_stream`.  A wait that runs out of `max_spins` sets bit r (r = late rank) in
@@ -267,7 +267,7 @@ int dockauv_p2p_gather(const dockauv_p2p_plan* plan, const void* src, uint32_t s
  *   behind the step groups push the previous rows while the step groups integrate: the fabric transfer is hidden
  *   behind the arithmetic, one launch per step); the last gather gets a kernel of its own.  Needs >= 4 plans, float
  *   kernels, slices that are multiples of 16 bytes.
- * gather_stream != compute_stream (lag ignored): gather kernels on a second stream beside the next step kernel; the step
+ * gather_stream != compute_stream (lag 0 or 1 = which stamp a gather awaits): gather kernels on a second stream beside the next step kernel; the step
  *   kernel that next writes the same row buffer waits for that gather.  Five stream/event calls per step on the host
  *   and two cross-stream dependencies: measured slower than one stream at every size on one GPU.
  */

@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 N=${1:-2}
 export WORLD_SIZE=$N LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=296$((RANDOM % 90 + 10)) DOCKAUV_DIST_BACKEND=gloo
-for mode in "--gather auto" "--gather auto --no-overlap" "--gather rccl"; do
+for mode in "--gather auto" "--gather auto --no-overlap"; do
   pids=()
   for r in $(seq 0 $((N - 1))); do
     RANK=$r timeout -k 10 300 python bench.py --gpus $N --steps 1000 --warmup 100 --no-cpu --no-sweep $mode \
