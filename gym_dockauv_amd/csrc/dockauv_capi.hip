@@ -308,6 +308,15 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
     if (c.n_vehicles < 1 || c.n_vehicles > 2) return fail(nullptr, DOCKAUV_E_INVALID, "n_vehicles must be 1 or 2");
     if (c.max_capsules < 0 || c.max_capsules > DOCKAUV_MAX_CAPSULES) return fail(nullptr, DOCKAUV_E_INVALID, "max_capsules out of range");
     if (c.max_spheres < 0 || c.max_spheres > DOCKAUV_MAX_SPHERES) return fail(nullptr, DOCKAUV_E_INVALID, "max_spheres out of range");
+    {
+        // the kernel forms SoA row offsets in 32-bit arithmetic: row * stride * sizeof(T) must stay below 2^32
+        const uint64_t stride = ((uint64_t)c.n_envs + 63) / 64 * 64;
+        uint64_t rows = 12;
+        if ((uint64_t)c.max_capsules * 7 > rows) rows = (uint64_t)c.max_capsules * 7;
+        if ((uint64_t)c.max_spheres * 4 > rows) rows = (uint64_t)c.max_spheres * 4;
+        if (rows * stride * (c.precision == DOCKAUV_F64 ? 8 : 4) >= (1ull << 32))
+            return fail(nullptr, DOCKAUV_E_INVALID, "n_envs too large for one handle (an SoA array would exceed 4 GiB): shard the batch over several handles");
+    }
     if (c.n_v <= 0 || c.n_h <= 0 || (long)c.n_v * c.n_h > DOCKAUV_MAX_RAYS) return fail(nullptr, DOCKAUV_E_INVALID, "bad ray fan %d x %d", c.n_v, c.n_h);
     if (c.blocksize_reduce <= 0) return fail(nullptr, DOCKAUV_E_INVALID, "blocksize_reduce must be > 0");
     if (c.reward_set != 1 && c.reward_set != 2) return fail(nullptr, DOCKAUV_E_INVALID, "reward_set must be 1 or 2");
