@@ -80,3 +80,21 @@ def test_bad_config_rejected(lib):
     h = C.c_void_p()
     rc = lib.dockauv_create(C.byref(cfg), 0, C.byref(h))
     assert rc == -1 and b"mismatch" in lib.dockauv_last_error(None)
+
+
+def test_oversized_batch_rejected(lib):
+    """SoA row offsets are 32-bit in the kernel: a handle whose arrays would reach 4 GiB is refused at create."""
+    from gym_dockauv_amd import _capi
+    cfg = _capi.Config()
+    cfg.struct_size = C.sizeof(_capi.Config)
+    cfg.abi_version = _capi.ABI_VERSION
+    cfg.n_envs = 2_000_000_000
+    cfg.precision = _capi.F32
+    cfg.n_vehicles = 1
+    h = C.c_void_p()
+    rc = lib.dockauv_create(C.byref(cfg), 0, C.byref(h))
+    assert rc == -1 and b"too large for one handle" in lib.dockauv_last_error(None)
+    # the p2p entry points validate their arguments before they touch a device
+    assert lib.dockauv_p2p_push(None, 16, None, 1, None) == -1
+    assert lib.dockauv_p2p_gather(None, None, 1, 1, None) == -1
+    assert b"dockauv_p2p_gather" in lib.dockauv_last_error(None)
