@@ -118,8 +118,8 @@ def cpu_baseline_all_cores(args, seconds: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=20000)     # 0.12 s at 6 us per step: short hiccups of a box average out
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (0 = the config's size)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
