@@ -75,3 +75,90 @@ class TorchDocking3d:
 
     def close(self) -> None:
         self.batch.close()
+
+
+class ShardedTorchDocking3d:
+    """
+    The same loop over several GPUs, one process per GPU, for a single learner: ``num_envs`` is
+    the TOTAL over the ranks of the ``torch.distributed`` group, rank r owns the contiguous range
+    ``shard_range(num_envs, world, r)``; ``step`` takes the learner's action batch (global ``[num_envs, n_u]`` -- the
+    rank's rows are sliced out in place -- or just the local rows), steps the rank's shard and returns GLOBAL
+    ``(obs, reward, done)``: every rank's packed rows, gathered by the peer-to-peer transport (``transport="p2p"``,
+    gym_dockauv_amd/parallel.py: P2PGather, closed loop: all rows of step t are there when the returned views are read
+    on the current stream) or by one RCCL all-gather (``"rccl"``).  The views stay valid for two further steps (p2p)
+    / until the next step (rccl).
+
+        dist.init_process_group("nccl", ...)
+        env = ShardedTorchDocking3d(TRAIN_CONFIG, num_envs=8 * 32768, scenario="ObstaclesDocking3d", device=local_rank)
+        obs = env.reset()
+        obs, reward, done = env.step(policy(obs))        # obs: [262144, n_obs] on every rank
+    """
+
+    def __init__(self, env_config: dict = BASE_CONFIG, num_envs: int = 4096, scenario: str = "SimpleDocking3d",
+                 device: int = 0, transport: str = "p2p", group=None, device_seed: int = 0, host_seed: Optional[int] = None,
+                 vehicles=None, **kw):
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+        from ..parallel import P2PShardedStepper, ShardedStepper, shard_range
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("ShardedTorchDocking3d needs an MI355X: no HIP device visible (there is no CPU fallback)")
+        if transport not in ("p2p", "rccl"):
+            raise ValueError("transport must be 'p2p' or 'rccl'")
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        if num_envs % self.world:
+            raise ValueError("num_envs must be a multiple of the number of ranks (equal shards)")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.num_envs = int(num_envs)
+        self.first, self.n_local = shard_range(self.num_envs, self.world, self.rank)
+        if vehicles is not None:
+            vehicles = list(vehicles)[self.first:self.first + self.n_local]
+        self.batch = BatchedDocking3d(env_config, num_envs=self.n_local, scenario=scenario, device=device, precision="f32",
+                                      reset_mode="device", device_seed=device_seed + self.rank, rng="batched",
+                                      vehicles=vehicles, **kw)
+        if host_seed is not None:
+            self.batch._gen = np.random.default_rng(host_seed + self.rank)
+        self.n_obs, self.n_u = self.batch.n_observations, self.batch.n_u
+        self.observation_space, self.action_space = self.batch.observation_space, self.batch.action_space
+        self.transport = transport
+
+        def step_fn(actions_local, out_local):
+            self.batch.step_device(actions_local.data_ptr(), out_local.data_ptr(),
+                                   stream=torch.cuda.current_stream().cuda_stream, packed=True)
+
+        if transport == "p2p":
+            self.stepper = P2PShardedStepper(self.n_local, self.n_obs + 2, step_fn, self.device, world=self.world,
+                                             rank=self.rank, group=group, overlap=False)
+        else:
+            self.stepper = ShardedStepper(self.n_local, self.n_obs + 2, step_fn, self.device, world=self.world,
+                                          rank=self.rank, group=group, overlap=False)
+        self._zeros = None
+
+    def reset(self, seed: Optional[int] = None):
+        """All envs of this rank's shard: new episodes; returns the reference's reset observation for ALL envs (zeros,
+        docking3d.py:269,322)."""
+        self.batch.reset(seed=seed)
+        if self._zeros is None:
+            self._zeros = self.torch.zeros((self.num_envs, self.n_obs), device=self.device, dtype=self.torch.float32)
+        return self._zeros
+
+    def step(self, actions):
+        """actions: contiguous float32 on this device, [num_envs, n_u] (global; this rank's rows are used) or
+        [n_local, n_u].  Returns global (obs [num_envs, n_obs], reward [num_envs], done [num_envs] bool) views."""
+        torch = self.torch
+        if actions.device != self.device or actions.dtype != torch.float32 or not actions.is_contiguous():
+            raise ValueError(f"actions must be a contiguous float32 tensor on {self.device}")
+        if tuple(actions.shape) == (self.num_envs, self.n_u) and self.world > 1:
+            actions = actions[self.first:self.first + self.n_local]
+        elif tuple(actions.shape) != (self.n_local, self.n_u):
+            raise ValueError(f"actions must be [{self.num_envs}, {self.n_u}] (global) or [{self.n_local}, {self.n_u}] (local)")
+        buf = self.stepper.step(actions)
+        return buf[:, : self.n_obs], buf[:, self.n_obs], buf[:, self.n_obs + 1] > 0.5
+
+    def close(self) -> None:
+        if hasattr(self.stepper, "close"):
+            self.stepper.close()
+        self.batch.close()

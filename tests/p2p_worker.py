@@ -126,6 +126,38 @@ def main() -> int:
             st.close()
         for e in envs:
             e.close()
+        # closed-loop learner surface: ShardedTorchDocking3d.step returns ALL ranks' rows; a toy policy closes the loop
+        from gym_dockauv_amd.envs.torch_env import ShardedTorchDocking3d
+        sh = ShardedTorchDocking3d(BASE_CONFIG, num_envs=world * n_local, scenario="SimpleCurrentDocking3d", device=0,
+                                   transport="p2p", device_seed=900, host_seed=70)
+        mir = []
+        for r in range(world):
+            e = BatchedDocking3d(BASE_CONFIG, num_envs=n_local, scenario="SimpleCurrentDocking3d", device=0, precision="f32",
+                                 reset_mode="device", device_seed=900 + r, rng="batched")
+            e._gen = np.random.default_rng(70 + r)
+            e.reset()
+            mir.append(e)
+        obs = sh.reset()
+        W = torch.linspace(-1, 1, sh.n_obs * sh.n_u, device=dev).reshape(sh.n_obs, sh.n_u)
+        exp = torch.zeros((world, n_local, row), device=dev)
+        exp_obs = torch.zeros((world * n_local, sh.n_obs), device=dev)
+        for t in range(steps):
+            a = torch.tanh(obs @ W + 0.1 * t).contiguous()              # same on every rank: obs is global
+            a_exp = torch.tanh(exp_obs @ W + 0.1 * t).contiguous()
+            obs, rew, done = sh.step(a)
+            for r in range(world):
+                mir[r].step_device(a_exp[r * n_local:(r + 1) * n_local].contiguous().data_ptr(), exp[r].data_ptr(), stream=stream, packed=True)
+            e2 = exp.reshape(world * n_local, row)
+            exp_obs = e2[:, :sh.n_obs].clone()
+            if not (torch.equal(obs.view(torch.int32), e2[:, :sh.n_obs].contiguous().view(torch.int32))
+                    and torch.equal(rew, e2[:, sh.n_obs]) and torch.equal(done, e2[:, sh.n_obs + 1] > 0.5)):
+                bad += 1
+                print(f"rank {rank} sharded env step {t}: global rows differ", flush=True)
+        assert sh.stepper.gather.timed_out() == 0
+        dist.barrier()
+        sh.close()
+        for e in mir:
+            e.close()
         print(f"rank {rank}: gathered steps checked, {bad} bad", flush=True)
         return 1 if bad else 0
     finally:

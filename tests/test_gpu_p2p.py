@@ -108,3 +108,34 @@ def test_sequence_argument_checks():
     assert g.timed_out() == 0
     st.close()
     env.close()
+
+
+def test_sharded_env_single_rank_equals_torch_env():
+    """ShardedTorchDocking3d with one rank (both transports) hands out what TorchDocking3d does, bit for bit."""
+    import numpy as np
+    import torch
+    from gym_dockauv_amd.envs.batched import BASE_CONFIG
+    from gym_dockauv_amd.envs.torch_env import ShardedTorchDocking3d, TorchDocking3d
+    dev = torch.device("cuda", 0)
+    n = 320
+    ref = TorchDocking3d(BASE_CONFIG, num_envs=n, scenario="CapsuleCurrentDocking3d", device_seed=5)
+    ref.batch._gen = np.random.default_rng(21)
+    ref.reset()
+    envs = [ShardedTorchDocking3d(BASE_CONFIG, num_envs=n, scenario="CapsuleCurrentDocking3d", transport=tr,
+                                  device_seed=5, host_seed=21) for tr in ("p2p", "rccl")]
+    for e in envs:
+        assert e.n_local == n and e.first == 0
+        assert torch.count_nonzero(e.reset()) == 0
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    for t in range(25):
+        a = torch.rand((n, ref.n_u), device=dev, generator=gen) * 2 - 1
+        o0, r0, d0 = ref.step(a)
+        for e in envs:
+            o, r, d = e.step(a)
+            assert torch.equal(o.view(torch.int32), o0.contiguous().view(torch.int32)) and torch.equal(r, r0) and torch.equal(d, d0)
+    with pytest.raises(ValueError):
+        envs[0].step(torch.zeros((n + 1, ref.n_u), device=dev))
+    for e in envs:
+        e.close()
+    ref.close()
