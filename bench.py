@@ -131,7 +131,7 @@ def main():
                     help="N > 1: transport of the per-step gather.  auto = peer-to-peer push (dockauv_p2p_*) if it maps "
                          "and reproduces the RCCL all-gather bit for bit during warm-up, else RCCL")
     ap.add_argument("--no-sweep", action="store_true")
-    ap.add_argument("--sweep", type=int, nargs="*", default=[65536, 1048576])
+    ap.add_argument("--sweep", type=int, nargs="*", default=[65536, 262144, 1048576])
     args = ap.parse_args()
     if args.cpu_worker:      # oracle loop only: no torch, no GPU
         print(cpu_baseline(workload(args.config, 1), args.cpu_seconds)["value"])
