@@ -7,7 +7,7 @@ export WORLD_SIZE=$N LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=296$((RANDOM
 for mode in "--gather auto" "--gather auto --no-overlap"; do
   pids=()
   for r in $(seq 0 $((N - 1))); do
-    RANK=$r timeout -k 10 300 python bench.py --gpus $N --steps 1000 --warmup 100 --no-cpu --no-sweep $mode \
+    RANK=$r timeout -k 10 300 python bench.py --gpus $N --steps ${STEPS:-1000} --warmup ${WARMUP:-100} --no-cpu --no-sweep $mode \
       > gpurun_out/ranks_${N}_r$r.out 2> gpurun_out/ranks_${N}_r$r.err &
     pids+=($!)
   done
