@@ -295,6 +295,22 @@ def main():
             seq_cache.clear()
             dt = timed_region(args.warmup, 0)
 
+    # for comparison: the same steps with the RCCL all-gather as the transport (short region, reported beside `value`)
+    rccl_ms = None
+    if transport == "p2p" and os.environ.get("DOCKAUV_DIST_BACKEND", "nccl") != "gloo":   # (gloo rehearsal: far too slow)
+        k2 = min(args.steps, 2000)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(k2):
+            rccl_stepper.step(actions[i % RING])
+        rccl_stepper.wait()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rccl_ms = float(t.item()) / k2 * 1e3
+
     # roofline of the dominant (only) kernel: per-dispatch start/stop events on the launch stream, cycling through
     # the same action ring as the timed region
     out_l = stepper.rows if transport == "p2p" else stepper.local_slice(stepper.bufs[0])
@@ -372,6 +388,7 @@ def main():
                        "auto_reset": "in-kernel scenario generation (Philox4x32-10)",
                        "collective": collective,
                        **({"gather_note": p2p_note} if p2p_note else {}),
+                       **({"rccl_all_gather_ms_per_step": rccl_ms} if rccl_ms is not None else {}),
                        "obs_finite": finite, "done_last_step_rank0": n_done},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
