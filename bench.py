@@ -2,25 +2,32 @@
 """
 bench.py -- env-steps/s of the batched docking3d step() on N MI355X (BASELINE.json metric), one process per GPU.
 
-  python bench.py --gpus 1 --steps K --warmup W                       (defaults finish in about a minute)
+  python bench.py --gpus 1 --steps K --warmup W                       (defaults finish in a few minutes)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
 A "step" is one launch of the fused HIP step kernel over this rank's envs (weak scaling: the per-GPU env count is
 fixed; at N = 1 the K launches of a region are queued by one dockauv_step_sequence call), followed -- for N > 1 --
-by one RCCL all-gather of [obs | reward | done] over xGMI so that a single learner
-sees all observations.  Inputs (actions) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+by one gather of [obs | reward | done] over xGMI so that a single learner sees all observations.  Inputs (actions)
+are resident in HBM before the timed region.  A timed region is EXACTLY K steps between barrier + synchronize on both
+sides (max over ranks); regions are repeated until --min-seconds have been measured and the MEDIAN region is
+reported (`reps`, `ms_per_step_first_region` and `ms_per_step_min` beside it), so that a short --steps is meaningful.
+Rank 0 prints ONE JSON line.
 
 Workloads (--config):
-  2  BlueROV2, SimpleDocking3d, 4 096 envs/GPU, no obstacles (pure 6-DOF RKF45 + reward)      [default]
-  3  BlueROV2, 16-beam fan vs 8 spheres, 65 536 envs/GPU
-  4  LAUV, ObstaclesDocking3d (5 capsules, 63 rays), t_step_size 0.02, 32 768 envs/GPU
-  5  BlueROV2/LAUV 50/50, ObstaclesCurrentDocking3d, t_step_size 0.02, 65 536 envs/GPU
+  2  BlueROV2, SimpleDocking3d, 4 096 envs/GPU, no obstacles (pure 6-DOF RKF45 + reward)
+  3  BlueROV2, 16-beam fan vs 8 spheres, 65 536 envs/GPU          [default at N = 1: the largest single-GPU config]
+  4  LAUV, ObstaclesDocking3d (5 capsules, 63 rays), t_step_size 0.02, 32 768 envs/GPU      [default at N > 1]
+  5  BlueROV2/LAUV 50/50, ObstaclesCurrentDocking3d, current speed U(0,1), t_step_size 0.02, 65 536 envs/GPU
+At N = 1 the line also carries `configs`: the same measurement (open-loop rate, kernel duration by HIP events,
+roofline, closed-loop rate) of config 2 at 4 096 envs and of the per-GPU shards of configs 4 and 5.
 """
 import argparse
 import copy
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,6 +38,9 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES = {2: 356, 3: 420, 4: 460, 5: 482}   # algorithmic bytes per env-step
 HBM_PEAK_GBPS = 8000.0                           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD = 1024                                    # 256 CUs x 4 SIMDs
+CLOCK_MHZ = 2400.0                               # max shader clock (MI355X_MICROARCH.md)
+VALU_CYCLES_PER_INST = 4.0                       # issue slots a wave64 VALU instruction is priced at (x4)
 
 
 def workload(config_id: int, envs: int):
@@ -38,61 +48,92 @@ def workload(config_id: int, envs: int):
     cfg = copy.deepcopy(BASE_CONFIG)
     fan16 = {"alpha": 30 * np.pi / 180, "beta": 30 * np.pi / 180, "ray_per_deg": 10 * np.pi / 180}
     if config_id == 2:
-        return dict(cfg=cfg, scenario="SimpleDocking3d", envs=envs or 4096, vehicles=None,
+        return dict(id=2, cfg=cfg, scenario="SimpleDocking3d", envs=envs or 4096, vehicles=None, current_speed=None,
                     name="config2: BlueROV2 SimpleDocking3d, no sensors, h=0.1")
     if config_id == 3:
         cfg["radar"].update(fan16)
-        return dict(cfg=cfg, scenario="SphereDocking3d", envs=envs or 65536, vehicles=None,
+        return dict(id=3, cfg=cfg, scenario="SphereDocking3d", envs=envs or 65536, vehicles=None, current_speed=None,
                     name="config3: BlueROV2 + 16-beam fan vs 8 spheres, h=0.1")
     if config_id == 4:
         cfg["vehicle"] = "LAUV"
         cfg["t_step_size"] = 0.02
-        return dict(cfg=cfg, scenario="ObstaclesDocking3d", envs=envs or 32768, vehicles=None,
+        return dict(id=4, cfg=cfg, scenario="ObstaclesDocking3d", envs=envs or 32768, vehicles=None, current_speed=None,
                     name="config4: LAUV ObstaclesDocking3d (5 capsules, 63 rays), h=0.02")
     if config_id == 5:
         cfg["t_step_size"] = 0.02
         n = envs or 65536
         if os.environ.get("DOCKAUV_CONFIG5_SORTED") == "1":
             # vehicle-sorted layout: first half BlueROV2, second half LAUV -> every wave but one is homogeneous
-            return dict(cfg=cfg, scenario="ObstaclesCurrentDocking3d", envs=n,
+            return dict(id=5, cfg=cfg, scenario="ObstaclesCurrentDocking3d", envs=n, current_speed="uniform01",
                         vehicles=["BlueROV2"] * (n // 2) + ["LAUV"] * (n - n // 2),
-                        name="config5: BlueROV2/LAUV vehicle-sorted, ObstaclesCurrentDocking3d, h=0.02")
-        return dict(cfg=cfg, scenario="ObstaclesCurrentDocking3d", envs=n,
+                        name="config5: BlueROV2/LAUV vehicle-sorted, ObstaclesCurrentDocking3d, V_c~U(0,1), h=0.02")
+        return dict(id=5, cfg=cfg, scenario="ObstaclesCurrentDocking3d", envs=n, current_speed="uniform01",
                     vehicles=["BlueROV2" if i % 2 == 0 else "LAUV" for i in range(n)],
-                    name="config5: BlueROV2/LAUV interleaved, ObstaclesCurrentDocking3d, h=0.02")
+                    name="config5: BlueROV2/LAUV interleaved, ObstaclesCurrentDocking3d, V_c~U(0,1), h=0.02")
     raise SystemExit(f"unknown --config {config_id}")
 
 
+def kernel_source_sha() -> str:
+    """Identifies the kernel version a profile under profiles/ belongs to."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gym_dockauv_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".inc", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def pmc_entry(config_id: int, envs: int):
+    """Counters of the step kernel for this workload from the committed rocprofv3 --pmc passes (scripts/profile_round.sh
+    -> profiles/pmc_counters.json): they are NOT measured in this run, so the entry carries its source."""
+    path = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    try:
+        e = json.load(open(path)).get(f"config{config_id}_envs{envs}")
+    except Exception:
+        return None
+    return e
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(wl, seconds: float):
     """The NumPy oracle (a port of the reference's per-env NumPy path) timed on this host, one core, on a bounded
-    sample of the same workload.  Reported next to the GPU number; it is NOT on the product path."""
+    sample of the same workload (same scenario, vehicle, fan, step size).  Reported next to the GPU number; it is
+    NOT on the product path."""
     from oracle import dockauv_oracle as orc
-    scenario = wl["scenario"] if wl["scenario"] in orc.SCENARIOS else "SimpleDocking3d"
-    veh = wl["cfg"]["vehicle"]
-    env = orc.OracleEnv(scenario, {"vehicle": veh, "t_step_size": wl["cfg"]["t_step_size"],
-                                   "radar": {k: wl["cfg"]["radar"][k] for k in ("alpha", "beta", "ray_per_deg", "max_dist")}})
-    env.reset(seed=0)
-    n_u = env.model.n_u
+    scenario = wl["scenario"]
+    if scenario not in orc.SCENARIOS:
+        raise SystemExit(f"oracle has no scenario {scenario}")
+    vehs = sorted(set(wl["vehicles"])) if wl["vehicles"] else [wl["cfg"]["vehicle"]]
+    envs = []
+    for veh in vehs:
+        e = orc.OracleEnv(scenario, {"vehicle": veh, "t_step_size": wl["cfg"]["t_step_size"],
+                                     "radar": {k: wl["cfg"]["radar"][k] for k in ("alpha", "beta", "ray_per_deg", "max_dist")}})
+        e.reset(seed=0)
+        envs.append(e)
     rs = np.random.RandomState(1234)
-    for _ in range(50):
-        _, _, d, _ = env.step(rs.uniform(-1, 1, n_u))
-        if d:
-            env.reset()
+
+    def some_steps(k):
+        for e in envs:
+            for _ in range(k):
+                _, _, d, _ = e.step(rs.uniform(-1, 1, e.model.n_u))
+                if d:
+                    e.reset()
+    some_steps(50)
     n = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        for _ in range(100):
-            _, _, d, _ = env.step(rs.uniform(-1, 1, n_u))
-            if d:
-                env.reset()
-        n += 100
+        some_steps(50)
+        n += 50 * len(envs)
     dt = time.perf_counter() - t0
+    n_sph = len(envs[0].sphere_radii)
     return {"value": n / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/dockauv_oracle.py (NumPy, float64, 1 env, 1 core), {n} steps of {scenario}/{veh} "
-                      f"in {dt:.1f} s, uniform random actions, reset on done"}
+            "sample": f"oracle/dockauv_oracle.py (NumPy, float64, 1 core), {n} steps of {scenario}/{'+'.join(vehs)} "
+                      f"({envs[0].fan.n_rays} rays, {len(envs[0].capsules)} capsules, {n_sph} spheres) in {dt:.1f} s, "
+                      f"uniform random actions, reset on done",
+            "reference_numpy_measured_in_survey": "~270 env-steps/s/core (SimpleDocking3d), ~250 (ObstaclesDocking3d): BASELINE.md section 2"}
 
 
-def cpu_baseline_all_cores(args, seconds: float):
+def cpu_baseline_all_cores(config_id: int, seconds: float):
     """The same oracle loop in one child process per CPU of this host (independent envs, as SURVEY.md section 8d asks);
     children never touch the GPU.  Returns (aggregate env-steps/s, processes)."""
     import subprocess
@@ -101,7 +142,7 @@ def cpu_baseline_all_cores(args, seconds: float):
     except AttributeError:
         avail = os.cpu_count() or 1
     procs = max(1, min(avail, 16))   # a one-GPU box's CPU share is 16 cores
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--config", str(args.config),
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "--config", str(config_id),
            "--cpu-seconds", str(seconds)]
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
     children = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(procs)]
@@ -115,15 +156,162 @@ def cpu_baseline_all_cores(args, seconds: float):
     return total, procs
 
 
+# ------------------------------------------------------------------------------------------ GPU helpers
+def make_env(wl, local_rank: int, rank: int, threads: int):
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    from gym_dockauv_amd import _capi
+    env = BatchedDocking3d(wl["cfg"], num_envs=wl["envs"], scenario=wl["scenario"], device=local_rank, precision="f32",
+                           reset_mode="device", device_seed=0x5EED0000 + rank, rng="batched", vehicles=wl["vehicles"],
+                           threads_per_group=threads)
+    env._gen = np.random.default_rng(1000 + rank)
+    env.reset()
+    if wl["current_speed"] == "uniform01":
+        # per-env current speed U(0, 1) (the scenario itself fixes 0.5 m/s, docking3d.py:985);
+        # V_min = V_max = V_c as in SimpleCurrentDocking3d (docking3d.py:844-848).  Episodes generated in-kernel after
+        # a reset use the scenario's own 0.5 m/s.
+        cur = env.get_field(_capi.F_CURRENT)
+        v = np.random.default_rng(77 + rank).random(wl["envs"])
+        cur[:, 0] = cur[:, 1] = cur[:, 2] = v
+        env.set_field(_capi.F_CURRENT, cur)
+    return env
+
+
+def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha: str):
+    bytes_per_launch = ALGO_BYTES[config_id] * envs
+    achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+         "traffic": None, "kernel": "dockauv::step_kernel", "kernel_us": kernel_us,
+         "algorithmic_bytes_per_env_step": ALGO_BYTES[config_id], "envs_per_launch": envs,
+         "timing": f"hipExtLaunchKernel start/stop events on the launch stream, {n_timed} launches"}
+    e = pmc_entry(config_id, envs)
+    if e:
+        stale = e.get("kernel_sha") != ksha
+        r["traffic"] = e.get("traffic_bytes")
+        r["traffic_source"] = (f"{e.get('source', 'profiles/pmc_counters.json')} (rocprofv3 --pmc passes of kernel "
+                               f"{e.get('kernel_sha')}, not this run" + ("; THIS library is a later kernel version" if stale else "") + ")")
+        if e.get("traffic_bytes"):
+            r["traffic_over_algorithmic"] = e["traffic_bytes"] / bytes_per_launch
+        if e.get("sq_insts_valu"):
+            cyc = kernel_us * CLOCK_MHZ
+            r["valu_frac"] = e["sq_insts_valu"] * VALU_CYCLES_PER_INST / (N_SIMD * cyc)
+            r["valu_frac_inputs"] = {"SQ_INSTS_VALU_per_launch": e["sq_insts_valu"], "cycles_per_inst": VALU_CYCLES_PER_INST,
+                                     "simds": N_SIMD, "kernel_cycles_at_2400MHz": cyc}
+    return r
+
+
+def timed_regions(run, steps, warmup_steps, warm_i0, min_seconds, max_reps, sync, barrier, reduce_max):
+    """Warm up, then time regions of EXACTLY `steps` steps (barrier + synchronize on both sides, max over ranks) until
+    `min_seconds` have been measured.  Returns the list of region durations."""
+    if warmup_steps > 0:
+        run(warmup_steps, warm_i0)
+    times = []
+    while True:
+        sync(); barrier(); sync()
+        t0 = time.perf_counter()
+        run(steps, warm_i0 + warmup_steps)
+        sync(); barrier(); sync()
+        times.append(reduce_max(time.perf_counter() - t0))
+        if sum(times) >= min_seconds or len(times) >= max_reps:
+            return times
+
+
+def closed_loop_rate(env, torch, dev, N, n_obs, n_u, steps):
+    """Closed loop: the actions of step t + 1 are computed ON THE DEVICE from the observations of step t (a linear
+    policy + tanh: torch kernels between the step kernels).  Two forms: issued step by step from Python, and the same
+    K steps captured once in a HIP graph and replayed (no host work per step)."""
+    out = torch.zeros((N, n_obs + 2), device=dev, dtype=torch.float32)
+    W = torch.randn((n_obs, n_u), device=dev, generator=torch.Generator(device=dev).manual_seed(5)) * 0.3
+    res = {"policy": "tanh(obs @ W), torch on the same stream"}
+
+    def loop(k, stream):
+        for _ in range(k):
+            a = torch.tanh(out[:, :n_obs] @ W)
+            env.step_device(a.data_ptr(), out.data_ptr(), stream=stream, packed=True)
+        return a
+
+    s0 = torch.cuda.current_stream().cuda_stream
+    loop(20, s0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop(steps, s0)
+    torch.cuda.synchronize()
+    res["python_issued_us_per_step"] = (time.perf_counter() - t0) / steps * 1e6
+    try:
+        K = 50
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            keep = loop(K, torch.cuda.current_stream().cuda_stream)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        reps = max(1, steps // K)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        res["hip_graph_us_per_step"] = (time.perf_counter() - t0) / (reps * K) * 1e6
+        del keep, g
+    except Exception as ex:   # graph capture is an optimisation of the caller, not of the path
+        res["hip_graph_us_per_step"] = None
+        res["hip_graph_note"] = f"capture failed: {type(ex).__name__}: {ex}"[:200]
+        torch.cuda.synchronize()
+    best = min(v for v in (res["python_issued_us_per_step"], res.get("hip_graph_us_per_step")) if v)
+    res["us_per_step"] = best
+    res["env_steps_per_s"] = N / (best * 1e-6)
+    return res
+
+
+def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, kernel_launches=512):
+    """One workload on this GPU alone (no collective): open-loop regions, kernel duration by events, closed loop."""
+    wl = workload(config_id, envs)
+    N = wl["envs"]
+    env = make_env(wl, local_rank, rank, args.threads)
+    n_obs, n_u = env.n_observations, env.n_u
+    RING = 64 if N <= 65536 else 16
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    actions = torch.rand((RING, N, n_u), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
+    out = torch.zeros((N, n_obs + 2), device=dev, dtype=torch.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    cache = {}
+
+    def run(n, i0=0):
+        key = (n, i0 % RING)
+        if key not in cache:
+            cache[key] = env.make_step_sequence([actions[i % RING].data_ptr() for i in range(i0, i0 + n)], [out.data_ptr()] * n, packed=True)
+        env.run_step_sequence(cache[key], stream=stream)
+
+    times = timed_regions(run, args.steps, args.warmup, 0, args.min_seconds / 2, args.max_reps, torch.cuda.synchronize,
+                          lambda: None, lambda x: x)
+    med = statistics.median(times)
+    kernel_us = 0.0
+    for i in range(kernel_launches):
+        kernel_us += env.time_steps_device(actions[i % RING].data_ptr(), out.data_ptr(), steps=1, stream=stream, packed=True)
+    kernel_us /= kernel_launches
+    torch.cuda.synchronize()
+    finite = bool(torch.isfinite(out).all().item())
+    cl = closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400)
+    res = {"workload": wl["name"], "envs": N, "value": N * args.steps / med, "unit": "env-steps/s",
+           "ms_per_step": med / args.steps * 1e3, "reps": len(times), "kernel_us": kernel_us,
+           "roofline": roofline_of(config_id, N, kernel_us, kernel_launches, ksha),
+           "closed_loop": cl, "obs_finite": finite}
+    env.close()
+    del actions, out
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)     # 0.12 s at 6 us per step: short hiccups of a box average out
-    ap.add_argument("--warmup", type=int, default=2000)
-    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", type=int, default=0, help="0 = config 3 at N = 1, config 4 (32 768 envs per GPU) at N > 1")
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (0 = the config's size)")
+    ap.add_argument("--min-seconds", type=float, default=0.2, help="timed regions are repeated until this much has been measured")
+    ap.add_argument("--max-reps", type=int, default=4000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the sub-results of the other BASELINE configs")
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)   # child of cpu_baseline_all_cores
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the all-gather with the next kernel")
@@ -131,10 +319,10 @@ def main():
                     help="N > 1: transport of the per-step gather.  auto = peer-to-peer push (dockauv_p2p_*) if it maps "
                          "and reproduces the RCCL all-gather bit for bit during warm-up, else RCCL")
     ap.add_argument("--no-sweep", action="store_true")
-    ap.add_argument("--sweep", type=int, nargs="*", default=[65536, 262144, 1048576])
+    ap.add_argument("--sweep", type=int, nargs="*", default=[262144, 1048576])
     args = ap.parse_args()
     if args.cpu_worker:      # oracle loop only: no torch, no GPU
-        print(cpu_baseline(workload(args.config, 1), args.cpu_seconds)["value"])
+        print(cpu_baseline(workload(args.config or 3, 2), args.cpu_seconds)["value"])
         return
 
     import torch
@@ -148,10 +336,12 @@ def main():
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    config_id = args.config or (3 if world == 1 else 4)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("DOCKAUV_FORCE_DIST") == "1"   # the latter: 1-rank rehearsal of the RCCL path
     saved_stdout = None
+    backend = None
     if use_dist:
         # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the ONE JSON line
         sys.stdout.flush()
@@ -164,15 +354,12 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        backend = dist.get_backend()
 
-    from gym_dockauv_amd.envs.batched import BatchedDocking3d
-    wl = workload(args.config, args.envs)
+    ksha = kernel_source_sha()
+    wl = workload(config_id, args.envs)
     N = wl["envs"]
-    env = BatchedDocking3d(wl["cfg"], num_envs=N, scenario=wl["scenario"], device=local_rank, precision="f32",
-                           reset_mode="device", device_seed=0x5EED0000 + rank, rng="batched", vehicles=wl["vehicles"],
-                           threads_per_group=args.threads)
-    env._gen = np.random.default_rng(1000 + rank)
-    env.reset()
+    env = make_env(wl, local_rank, rank, args.threads)
     n_obs, n_u = env.n_observations, env.n_u
 
     # synthetic actions resident in HBM: a ring of distinct batches, uniform in [-1, 1] (counter RNG seeded 1234)
@@ -183,7 +370,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     # the kernel writes packed rows [obs | reward | done] (float32 [N][n_obs + 2]) straight into this rank's slice
-    # of the gather buffer; ONE all-gather per step, overlapped with the next step's kernel (two buffers)
+    # of the gather buffer; ONE gather per step, overlapped with the next step's kernel (two buffers)
     from gym_dockauv_amd.parallel import ShardedStepper
 
     def step_fn(a, out_local):
@@ -193,7 +380,6 @@ def main():
     stepper.use_dist = use_dist
     rccl_stepper = stepper
     transport, p2p_note, n_verify = ("rccl" if use_dist else "none"), None, 0
-    two_streams = False     # gathers on a second stream: measured slower on one GPU at every size (parallel.py)
     if use_dist and args.gather in ("auto", "p2p"):
         # peer-to-peer transport: accepted only if every rank mapped its peers AND the gathered rows of the first
         # warm-up steps equal an RCCL all-gather of the same rows bit for bit on every rank
@@ -238,8 +424,8 @@ def main():
             raise SystemExit(p2p_note)
 
     # Single GPU, no collective: the K steps of a region are queued by ONE host call (dockauv_step_sequence: K
-    # launches of the same kernel, step i reading actions[i % RING]), so that a 6 us kernel is not paced by ~7 us of
-    # Python per step.  With a collective in the loop the steps are issued one by one (the gather sits between them).
+    # launches of the same kernel, step i reading actions[i % RING]), so that a short kernel is not paced by ~7 us of
+    # Python per step.  With RCCL in the loop the steps are issued one by one (the gather sits between them).
     seq_cache = {}
 
     def run(n, i0=0):
@@ -252,7 +438,7 @@ def main():
             env.run_step_sequence(seq_cache[key], stream=stream)
             return
         if transport == "p2p" and not args.no_overlap:
-            # one host call: n step kernels on the compute stream, their gathers on a second stream
+            # one host call: n step kernels, the gather of step t riding in the grid of step kernel t + 1
             key = (n, i0 % RING, stepper.gather.t & 1)
             if key not in seq_cache:
                 seq_cache[key] = stepper.make_sequence(env, [actions[i % RING].data_ptr() for i in range(i0, i0 + n)])
@@ -262,28 +448,21 @@ def main():
             stepper.step(actions[i % RING])
         stepper.wait()
 
-    def timed_region(n_warm, i_warm):
-        run(n_warm, i_warm)
-        torch.cuda.synchronize()
+    def barrier():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(args.steps, args.warmup)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        dt_ = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt_], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt_ = float(t.item())
-        return dt_
 
-    dt = timed_region(max(0, args.warmup - n_verify), n_verify)
+    def reduce_max(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    times = timed_regions(run, args.steps, max(0, args.warmup - n_verify), n_verify, args.min_seconds, args.max_reps,
+                          torch.cuda.synchronize, barrier, reduce_max)
     if transport == "p2p":
-        # a stamp that did not arrive within the spin bound voids the region on every rank: measure again over RCCL
+        # a stamp that did not arrive within the spin bound voids the regions on every rank: measure again over RCCL
         late = torch.tensor([stepper.gather.timed_out()], device=dev, dtype=torch.int64)
         dist.all_reduce(late, op=dist.ReduceOp.MAX)
         if int(late.item()) != 0:
@@ -293,9 +472,12 @@ def main():
             stepper.close()
             stepper, transport = rccl_stepper, "rccl"
             seq_cache.clear()
-            dt = timed_region(args.warmup, 0)
+            times = timed_regions(run, args.steps, args.warmup, 0, args.min_seconds, args.max_reps,
+                                  torch.cuda.synchronize, barrier, reduce_max)
+    dt = statistics.median(times)
 
-    # for comparison: the same steps with the RCCL all-gather as the transport (short region, reported beside `value`)
+    # for comparison: the same steps with the RCCL all-gather as the transport, issued step by step from Python (the
+    # p2p regions are queued by one host call: the two paces differ by host pacing as well as by transport)
     rccl_ms = None
     if transport == "p2p" and os.environ.get("DOCKAUV_DIST_BACKEND", "nccl") != "gloo":   # (gloo rehearsal: far too slow)
         k2 = min(args.steps, 2000)
@@ -307,27 +489,26 @@ def main():
         rccl_stepper.wait()
         torch.cuda.synchronize()
         dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        rccl_ms = float(t.item()) / k2 * 1e3
+        rccl_ms = reduce_max(time.perf_counter() - t0) / k2 * 1e3
 
     # roofline of the dominant (only) kernel: per-dispatch start/stop events on the launch stream, cycling through
     # the same action ring as the timed region
     out_l = stepper.rows if transport == "p2p" else stepper.local_slice(stepper.bufs[0])
-    k_steps = min(args.steps, 1024)
+    n_timed = min(max(args.steps, 256), 1024)
     kernel_us = 0.0
-    for i in range(k_steps):
+    for i in range(n_timed):
         kernel_us += env.time_steps_device(actions[i % RING].data_ptr(), out_l.data_ptr(), steps=1, stream=stream, packed=True)
-    n_timed = k_steps
     kernel_us /= n_timed
     torch.cuda.synchronize()
     last = stepper.bufs[0]
     finite = bool(torch.isfinite(last).all().item())
     n_done = int((out_l[:, n_obs + 1] > 0.5).sum().item())
+    closed = closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400) if world == 1 and not use_dist else None
 
     sweep = []
     if world == 1 and not args.no_sweep and not args.envs:
         # the same kernel at batch sizes where the state no longer fits the caches (HBM-relevant roofline points)
+        from gym_dockauv_amd.envs.batched import BatchedDocking3d
         for n_big in args.sweep:
             e2 = BatchedDocking3d(wl["cfg"], num_envs=n_big, scenario=wl["scenario"], device=local_rank, precision="f32",
                                   reset_mode="device", device_seed=0xABC, rng="batched",
@@ -341,7 +522,7 @@ def main():
             torch.cuda.synchronize()
             us = sum(e2.time_steps_device(a2[r % 4].data_ptr(), o2.data_ptr(), steps=10, stream=stream, packed=True) for r in range(8)) / 8
             torch.cuda.synchronize()
-            gbps = ALGO_BYTES[args.config] * n_big / (us * 1e-6) / 1e9
+            gbps = ALGO_BYTES[config_id] * n_big / (us * 1e-6) / 1e9
             sweep.append({"envs": n_big, "kernel_us": us, "env_steps_per_s_kernel": n_big / (us * 1e-6),
                           "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS})
             e2.close()
@@ -361,16 +542,19 @@ def main():
                          if stepper._ride_ok else
                          "before step t + 1 starts (gather kernel after each step kernel, one host call per region)")
                       + f"; checked bit-exact against an rccl all_gather during the first {n_verify} warm-up steps")
+    devices = [torch.cuda.current_device()]
+    if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+                                          "name": torch.cuda.get_device_name(local_rank)})
+        devices = gathered
+    # release the headline env before the sub-results allocate theirs
+    if transport == "p2p":
+        stepper.close()
+    env.close()
+    del actions
+
     if rank == 0:
-        bytes_per_launch = ALGO_BYTES[args.config] * N
-        achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"config{args.config}_envs{N}")
-            except Exception:
-                traffic = None
         out = {
             "metric": "env-steps/sec (batched docking3d)",
             "value": world * N * args.steps / dt,
@@ -379,6 +563,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "reps": len(times),
+            "ms_per_step_first_region": times[0] / args.steps * 1e3,
+            "ms_per_step_min": min(times) / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -386,21 +573,33 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["name"], "envs_per_gpu": N, "total_envs": world * N, "n_obs": n_obs, "n_u": n_u,
                        "auto_reset": "in-kernel scenario generation (Philox4x32-10)",
+                       "timing": f"median of {len(times)} regions of {args.steps} steps (>= {args.min_seconds} s measured in all), "
+                                 "each between barrier + synchronize, max over ranks; open loop: actions from a ring resident in HBM",
                        "collective": collective,
+                       "world_size": (dist.get_world_size() if use_dist else 1), "backend": backend, "ranks": devices,
                        **({"gather_note": p2p_note} if p2p_note else {}),
-                       **({"rccl_all_gather_ms_per_step": rccl_ms} if rccl_ms is not None else {}),
-                       "obs_finite": finite, "done_last_step_rank0": n_done},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "dockauv::step_kernel", "kernel_us": kernel_us,
-                         "algorithmic_bytes_per_env_step": ALGO_BYTES[args.config], "envs_per_launch": N,
-                         "timing": f"hipExtLaunchKernel start/stop events on the launch stream, {n_timed} launches after the timed region"},
+                       **({"rccl_all_gather_ms_per_step_python_issued": rccl_ms} if rccl_ms is not None else {}),
+                       "obs_finite": finite, "done_last_step_rank0": n_done,
+                       "kernel_source_sha": ksha},
+            "roofline": roofline_of(config_id, N, kernel_us, n_timed, ksha),
         }
+        if closed:
+            out["closed_loop"] = closed
         if sweep:
             out["sweep"] = sweep
+        if world == 1 and not use_dist and not args.no_configs and not args.envs:
+            subs = []
+            for cid in (2, 3, 4, 5):
+                if cid == config_id:
+                    subs.append({"workload": wl["name"], "envs": N, "value": out["value"], "unit": "env-steps/s",
+                                 "ms_per_step": out["ms_per_step"], "reps": len(times), "kernel_us": kernel_us,
+                                 "roofline": out["roofline"], "closed_loop": closed, "headline": True})
+                else:
+                    subs.append(measure_single(cid, 0, args, torch, dev, local_rank, rank, ksha))
+            out["configs"] = subs
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)
-            allv, procs = cpu_baseline_all_cores(args, args.cpu_seconds)
+            allv, procs = cpu_baseline_all_cores(config_id, args.cpu_seconds)
             out["cpu_baseline"]["all_cores_value"] = allv        # one oracle process per CPU of this host
             out["cpu_baseline"]["all_cores"] = procs
         sys.stdout.flush()
@@ -409,9 +608,6 @@ def main():
         print(json.dumps(out), flush=True)
         if saved_stdout is not None:
             os.dup2(2, 1)
-    if transport == "p2p":
-        stepper.close()
-    env.close()
     if use_dist:
         dist.destroy_process_group()
 

@@ -847,7 +847,7 @@ int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_st
 }
 
 #ifdef DOCKAUV_STAMPS
-// diagnostic build only (scripts/stamps.py): 64 groups x 16 s_memtime stamps of the last f32 step
+// diagnostic build only (scripts/stamps.py): 64 groups x 32 s_memtime stamps of the last f32 step
 int dockauv_debug_read_stamps(unsigned long long* out) {
     (void)hipDeviceSynchronize();
     return dockauv::read_stamps(out);

@@ -144,7 +144,7 @@ constexpr int kHxFields = 21;    // env phase -> tail waves: state (12), V_c, ac
 
 template <typename T>
 inline size_t lds_bytes(int epg, int nt, int max_cap, int max_sph, int n_obs, bool rays) {
-    size_t t_elems = rays ? (size_t)epg * (kPoseFields + kCapFields * max_cap + kSphFields * max_sph + 3 * (nt / epg)) : 0;
+    size_t t_elems = rays ? (size_t)epg * (kPoseFields + kCapFields * max_cap + kSphFields * max_sph + 4 * (nt / epg)) : 0;
     if (nt / epg >= 2) t_elems += (size_t)epg * (kHxFields + kSpecFields);
     size_t bytes = t_elems * sizeof(T);
     bytes = (bytes + 15) & ~(size_t)15;

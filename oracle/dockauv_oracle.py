@@ -525,7 +525,8 @@ def default_config() -> dict:
 VEHICLE_KINDS = {"BlueROV2": "bluerov2", "BlueROV2_direct": "bluerov2_direct", "LAUV": "lauv"}
 
 SCENARIOS = ("SimpleDocking3d", "SimpleCurrentDocking3d", "CapsuleDocking3d", "CapsuleCurrentDocking3d",
-             "ObstaclesDocking3d", "ObstaclesNoCapDocking3d", "ObstaclesCurrentDocking3d")
+             "ObstaclesDocking3d", "ObstaclesNoCapDocking3d", "ObstaclesCurrentDocking3d", "SphereDocking3d")
+SPHERE_SEED = 10_000   # SphereDocking3d (build-defined, BASELINE config 3): obstacle field of episode k
 
 SAFETY_RADIUS = 1.0  # Q9: hard-wired, objects/auvsim.py:43 (config "radius" is ignored)
 
@@ -543,11 +544,25 @@ class Episode:
     sphere_radii: np.ndarray = field(default_factory=lambda: np.zeros(0))
 
 
-def generate_episode(scenario: str, rng: np.random.RandomState, max_attitude: float, max_dist_from_goal: float
-                     ) -> Episode:
+def sphere_field(rs: np.random.RandomState, goal: np.ndarray, n_spheres: int = 8, r_min: float = 3.0,
+                 r_max: float = 12.0) -> Tuple[np.ndarray, np.ndarray]:
+    """Obstacle field of the build-defined SphereDocking3d scenario (the reference
+    ships the sphere routines, objects/shape.py:235-264, but no env that uses them): centres uniform in direction,
+    distance U(r_min, r_max) from the goal, radii U(0.5, 1.5).  Same draws as SphereDocking3d.generate_environment
+    of oracle/gen_golden.py, which produced the traj_SphereDocking3d_* fixtures on the reference."""
+    d = rs.normal(size=(n_spheres, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    centers = np.asarray(goal, dtype=float)[None, :3] + d * rs.uniform(r_min, r_max, n_spheres)[:, None]
+    radii = rs.uniform(0.5, 1.5, n_spheres)
+    return centers, radii
+
+
+def generate_episode(scenario: str, rng: np.random.RandomState, max_attitude: float, max_dist_from_goal: float,
+                     sphere_rng: Optional[np.random.RandomState] = None) -> Episode:
     """
     Scenario generators with the reference's draw order on a legacy MT19937 stream.
     envs/docking3d.py:687-703 (random pos / att) and :795-988 (the seven scenarios).
+    SphereDocking3d = SimpleDocking3d + sphere_field(sphere_rng) (its own stream, as in oracle/gen_golden.py).
     """
     # --- SimpleDocking3d.generate_environment, docking3d.py:803-825
     goal = np.zeros(3)
@@ -561,6 +576,11 @@ def generate_episode(scenario: str, rng: np.random.RandomState, max_attitude: fl
     ep = Episode(position=position, attitude=attitude, goal=goal, heading_goal=heading, current=cur)
 
     if scenario == "SimpleDocking3d":
+        return ep
+    if scenario == "SphereDocking3d":
+        if sphere_rng is None:
+            raise ValueError("SphereDocking3d needs sphere_rng")
+        ep.sphere_centers, ep.sphere_radii = sphere_field(sphere_rng, ep.goal)
         return ep
     if scenario == "SimpleCurrentDocking3d":                                # docking3d.py:844-849
         ang = (rng.random_sample(2) - 0.5) * 2.0 * np.array([PI / 2, PI])
@@ -656,7 +676,9 @@ class OracleEnv:
             self.rng = np.random.RandomState(seed)
         self.episode += 1
         if episode is None:
-            episode = generate_episode(self.scenario, self.rng, self.cfg["max_attitude"], self.cfg["max_dist_from_goal"])
+            srng = np.random.RandomState(SPHERE_SEED + self.episode) if self.scenario == "SphereDocking3d" else None
+            episode = generate_episode(self.scenario, self.rng, self.cfg["max_attitude"], self.cfg["max_dist_from_goal"],
+                                       sphere_rng=srng)
         self.load_episode(episode)
         return self.observation
 

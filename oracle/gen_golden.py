@@ -534,6 +534,15 @@ def gen_trajectories():
              cfg_over=dict(lauv, max_timesteps=300), act_seed=13)
     run_traj("traj_ObstaclesCurrentDocking3d_lauv_random", "ObstaclesCurrentDocking3d", "LAUV", 63, 200,
              lambda rs: ctrl_random(rs), cfg_over=dict(lauv, max_timesteps=90), act_seed=14)
+    gen_mixed_partner()
+
+
+def gen_mixed_partner():
+    """BlueROV2 under the configuration of traj_ObstaclesCurrentDocking3d_lauv_random (h = 0.02, max_timesteps 90):
+    its rows interleaved with the LAUV rows are BASELINE config 5 (mixed 50/50 batch) checked directly against
+    the reference (tests/test_gpu_fullsize.py)."""
+    run_traj("traj_ObstaclesCurrentDocking3d_bluerov2_h002_random", "ObstaclesCurrentDocking3d", "BlueROV2", 64, 200,
+             lambda rs: ctrl_random(rs), cfg_over={"t_step_size": 0.02, "max_timesteps": 90}, act_seed=15)
 
 
 def gen_radar_layout():
@@ -563,6 +572,9 @@ def gen_radar_layout():
 
 if __name__ == "__main__":
     print("reference:", REF)
+    if "--mixed-partner-only" in sys.argv:    # added in round 2; the other fixtures are unchanged
+        gen_mixed_partner()
+        sys.exit(0)
     gen_constants()
     gen_state_dot()
     gen_auv_step()

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""In-kernel time line of the step kernel (diagnostic build: scripts/build_variant.py stamps -DDOCKAUV_STAMPS).
-usage: DOCKAUV_LIB=.../libdockauv_stamps.so python scripts/stamps.py [--config 2] [--envs 4096]"""
+"""In-kernel time line of the step kernel (diagnostic build:
+    python scripts/build_variant.py stamps -DDOCKAUV_STAMPS -DDOCKAUV_ROTATE_WAVES=0).
+usage: DOCKAUV_LIB=.../libdockauv_stamps.so python scripts/stamps.py [--config 2] [--envs 4096]
+Stamps a launch did not write (roles a configuration does not have) are masked, not printed."""
 import argparse, ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +12,7 @@ import bench
 from gym_dockauv_amd.envs.batched import BatchedDocking3d
 from gym_dockauv_amd import _capi
 
+NS = 32   # stamps per group
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=2)
 ap.add_argument("--envs", type=int, default=0)
@@ -25,28 +28,45 @@ a = torch.rand((8, N, env.n_u), device=dev) * 2 - 1
 out = torch.zeros((N, env.n_observations + 2), device=dev)
 stream = torch.cuda.current_stream().cuda_stream
 lib = _capi.load_library()
-names = ["start", "loads issued", "loads landed + nu_c", "RK step", "ray stage", "nav + obs", "reward", "outputs", "reset + write-back", "obs tile store"]
-acc = []
-raw = []
+G = min(64, (N + 63) // 64)
+runs = []
 for it in range(40):
     env.step_device(a[it % 8].data_ptr(), out.data_ptr(), stream=stream, packed=True)
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * (64 * 16))()
+    buf = (ctypes.c_ulonglong * (64 * NS))()
     rc = lib.dockauv_debug_read_stamps(buf)
     assert rc == 0, rc
-    raw.append(bytes(buf))
-    st = np.frombuffer(buf, dtype=np.uint64).reshape(64, 16)[:min(64, (N + 63) // 64), :10].astype(np.int64)
     if it >= 8:
-        acc.append(st)
-st = np.stack(acc)                       # [it, group, stamp]
-d = np.diff(st, axis=2)                  # s_memtime ticks at 100 MHz? (shader clock on gfx950: see MICROARCH) -> report raw
-print("s_memtime deltas per segment, median over groups and launches (ticks):")
-for i in range(9):
-    print(f"  {names[i]:>22s} -> {names[i+1]:<22s} {np.median(d[:, :, i]):9.0f}   (p10 {np.percentile(d[:, :, i], 10):7.0f}, p90 {np.percentile(d[:, :, i], 90):7.0f})")
-full = np.stack([np.frombuffer(b, dtype=np.uint64).reshape(64, 16)[:min(64, (N + 63) // 64)].astype(np.int64) for b in raw[8:]])
-if (full[:, :, 10] > 0).all():
-    print("second wave of the group (ray stage only), relative to the group's start stamp:")
-    for i, nm in ((14, "wave 0: part 1 done"), (15, "wave 0: records complete"), (10, "ray stage entered"), (11, "first cell done"), (12, "all cells done"), (13, "second barrier passed")):
-        print(f"  {nm:>24s} at {np.median(full[:, :, i] - full[:, :, 0]):9.0f}")
-print(f"  total {np.median(st[:, :, 9] - st[:, :, 0]):.0f} ticks; group start spread {np.median(st[:, :, 0].max(axis=1) - st[:, :, 0].min(axis=1)):.0f}")
+        runs.append(np.frombuffer(buf, dtype=np.uint64).reshape(64, NS)[:G].astype(np.int64).copy())
+st = np.stack(runs)                                   # [launch, group, stamp]
+rel = (st - st[:, :, :1]).astype(np.float64)          # relative to the group's start stamp
+# a stamp this launch did not write is zero or left over from an earlier launch: before this launch's start
+total = rel[:, :, 9:10].copy()
+rel[rel < 0] = np.nan
+
+
+def med(i):
+    with np.errstate(all="ignore"):
+        v = np.nanmedian(rel[:, :, i])
+    return v
+
+
+print(f"{wl['name']}  N={N}  (s_memtime ticks relative to the group's start; median over {G} groups x {len(runs)} launches)")
+wave0 = [(1, "loads issued"), (2, "loads landed, nu_c done"), (16, "inputs filtered (vehicle_step_)"), (17, "RHS 1"), (18, "RHS 2"),
+         (19, "RHS 3"), (20, "RHS 4"), (21, "RHS 5"), (3, "RK step done"), (14, "pose trig / publish"), (15, "obstacle records complete"),
+         (4, "ray stage done (wave 0)"), (5, "nav + obs done"), (7, "resetter entered"), (8, "reset + write-back issued"), (9, "obs tile stored = end")]
+prev = 0.0
+print("  wave 0 (integrating wave):")
+for i, nm in wave0:
+    v = med(i)
+    if np.isnan(v):
+        continue
+    print(f"    {nm:<34s} at {v:8.0f}   (+{v - prev:6.0f})")
+    prev = v
+print("  second wave of the group:")
+for i, nm in ((10, "ray stage entered / hand-over received"), (11, "first cell done / reward done"), (12, "all cells done / tail waves done"), (13, "barrier after the ray stage passed")):
+    v = med(i)
+    if not np.isnan(v):
+        print(f"    {nm:<42s} at {v:8.0f}")
+print(f"  total {np.nanmedian(total):.0f} ticks; group start spread within a launch {np.median(st[:, :, 0].max(axis=1) - st[:, :, 0].min(axis=1)):.0f}")
 env.close()

@@ -1,0 +1,90 @@
+"""
+Full-size parity (What's missing 4 and 5): each BASELINE config at its stated batch size, every env of the
+batch against the reference.  The golden steps of the config's trajectory (reference outputs, tests/golden) are tiled
+over the batch -- env j starts where golden step j % T started and gets that step's action -- one kernel launch of
+the float32 product path steps all of them, and EVERY env must reproduce its golden row (same tolerances and
+exclusion rules as the teacher-forced tests of tests/test_gpu_parity.py: 1e-5 on observations).
+
+  config 2: BlueROV2 SimpleDocking3d,            4 096 envs   <- traj_config1_simple_bluerov2
+  config 3: BlueROV2 + 16-beam fan + 8 spheres, 65 536 envs   <- traj_SphereDocking3d_bluerov2_fan16(_random)
+  config 4: LAUV ObstaclesDocking3d, h = 0.02,  32 768 envs   <- traj_ObstaclesDocking3d_lauv_goto
+  config 5: BlueROV2 / LAUV interleaved 50/50, ObstaclesCurrentDocking3d, h = 0.02, 65 536 envs (VK_MIXED kernel)
+            <- traj_ObstaclesCurrentDocking3d_bluerov2_h002_random (even envs) + ..._lauv_random (odd envs)
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def run_tiled(names, n_envs, precision="f32", threads=0):
+    """names: one golden trajectory, or two for a mixed batch (env j uses names[j % 2])."""
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    gs = [H.load(n) for n in names]
+    K = len(gs)
+    cfg = H.config_from_meta(gs[0])
+    for g in gs[1:]:
+        c2 = H.config_from_meta(g)
+        assert c2["t_step_size"] == cfg["t_step_size"] and c2["max_timesteps"] == cfg["max_timesteps"]
+        assert c2["radar"] == cfg["radar"] and H.scenario_of(g) == H.scenario_of(gs[0])
+    max_caps = max(int(g["ep_n_capsules"].max()) if g["ep_n_capsules"].size else 0 for g in gs)
+    max_sph = max(int(g["ep_sph_radii"].shape[1]) for g in gs)
+    vehicles = None
+    if K == 2:
+        vehicles = [str(gs[j % 2]["meta_vehicle"]) for j in range(n_envs)]
+        assert sorted(set(vehicles)) == ["BlueROV2", "LAUV"]
+    env = BatchedDocking3d(cfg, num_envs=n_envs, scenario=H.scenario_of(gs[0]), precision=precision, auto_reset=False,
+                           max_capsules=max_caps, max_spheres=max_sph, current_mu=float(gs[0]["ep_current"][0, 0]),
+                           vehicles=vehicles, threads_per_group=threads)
+    try:
+        # env j -> trajectory j % K, golden step (j // K) % T
+        parts = []
+        for k, g in enumerate(gs):
+            envs_k = np.arange(k, n_envs, K)
+            parts.append((envs_k, H.teacher_forced_inputs(g, (envs_k // K) % int(g["meta_T"]), max_caps, max_sph)))
+
+        def merge(get):
+            first = get(parts[0][1])
+            out = np.zeros((n_envs,) + first.shape[1:], dtype=first.dtype)
+            for envs_k, inp in parts:
+                out[envs_k] = get(inp)
+            return out
+        inp = {k: merge(lambda p, k=k: p[k]) for k in ("state", "u", "tsteps", "noise", "actions")}
+        inp["episodes"] = {k: merge(lambda p, k=k: p["episodes"][k]) for k in parts[0][1]["episodes"]}
+        gold = {k: merge(lambda p, k=k: p["gold"][k]) for k in parts[0][1]["gold"]}
+        H.load_teacher_forced(env, inp)
+        obs, rew, done, _ = env.step(inp["actions"][:, :env.n_u], noise=inp["noise"], extras=True)
+        res = H.check_teacher_forced(env, obs, rew, done, gold, precision, "+".join(names) + f" x{n_envs}")
+        # the batch is made of copies: copies of the same golden step must also agree with each other bit for bit
+        T0 = int(gs[0]["meta_T"]) * K
+        if n_envs >= 2 * T0:
+            assert np.array_equal(obs[:T0], obs[T0:2 * T0]) and np.array_equal(rew[:T0], rew[T0:2 * T0])
+        return res
+    finally:
+        env.close()
+
+
+def test_config2_full_size():
+    run_tiled(["traj_config1_simple_bluerov2"], 4096)
+
+
+@pytest.mark.parametrize("name", ["traj_SphereDocking3d_bluerov2_fan16", "traj_SphereDocking3d_bluerov2_fan16_random"])
+def test_config3_full_size(name):
+    run_tiled([name], 65536)
+
+
+def test_config4_full_size():
+    run_tiled(["traj_ObstaclesDocking3d_lauv_goto"], 32768)
+
+
+def test_config5_mixed_full_size():
+    run_tiled(["traj_ObstaclesCurrentDocking3d_bluerov2_h002_random", "traj_ObstaclesCurrentDocking3d_lauv_random"], 65536)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_config5_mixed_batch_vs_reference(precision):
+    """The mixed-vehicle kernel (VK_MIXED) directly against the reference's outputs, both precisions, small batch
+    (one copy of each golden step; float64 to 1e-9)."""
+    run_tiled(["traj_ObstaclesCurrentDocking3d_bluerov2_h002_random", "traj_ObstaclesCurrentDocking3d_lauv_random"], 400, precision)

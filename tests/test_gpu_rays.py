@@ -19,12 +19,12 @@ def _scene(rs):
     sph = np.zeros((N, MAX_SPH, 4))
     for i in range(N):
         for c in range(MAX_CAP):
-            ctr = pos[i] + rs.uniform(-14, 14, 3)
+            ctr = pos[i] + rs.uniform(-9, 9, 3)
             half = rs.normal(size=3)
             half *= rs.uniform(0.2, 12) / np.linalg.norm(half)
-            caps[i, c] = [*(ctr - half), *(ctr + half), rs.uniform(0.3, 2.5)]
+            caps[i, c] = [*(ctr - half), *(ctr + half), rs.uniform(0.5, 3.0)]
         for s in range(MAX_SPH):
-            sph[i, s] = [*(pos[i] + rs.uniform(-14, 14, 3)), rs.uniform(0.3, 3.0)]
+            sph[i, s] = [*(pos[i] + rs.uniform(-9, 9, 3)), rs.uniform(0.5, 3.5)]
         if i % 4 == 0:        # vehicle inside capsule 0 / sphere 0
             caps[i, 0, 0:3] = pos[i] + [0.2, -0.1, -3.0]
             caps[i, 0, 3:6] = pos[i] + [0.1, 0.3, 4.0]
@@ -70,6 +70,8 @@ def test_random_obstacle_geometry_vs_oracle(precision):
     d_ref = np.zeros_like(d_gpu)
     col_ref = np.zeros(N, dtype=bool)
     obs_ref = np.zeros_like(obs)
+    oracles_max_dist = orc.OracleEnv("CapsuleDocking3d").fan.max_dist
+    assert oracles_max_dist == env.radar.max_dist
     for i in range(N):
         o = orc.OracleEnv("CapsuleDocking3d")
         n_c = MAX_CAP if caps[i, 2, 6] > 0 else 2
@@ -82,21 +84,23 @@ def test_random_obstacle_geometry_vs_oracle(precision):
         d_ref[i], col_ref[i], obs_ref[i] = o.intersec_dist, o.collision, oo
         assert np.abs(o.state[0:3] - new_state[i, 0:3]).max() < (1e-9 if precision == "f64" else 2e-6)
 
-    md = 25.0
+    md = float(oracles_max_dist)                      # radar max_dist: a clamped distance < md is a hit in range
     err = np.abs(d_gpu - d_ref)
-    hit = (d_ref < md) | (d_gpu < md)
-    assert hit.mean() > 0.15, "the scene must exercise the intersection code"
+    hit_ref, hit_gpu = d_ref < md, d_gpu < md
+    assert hit_ref.mean() > 0.15, f"the scene must exercise the intersection code: {hit_ref.mean():.3f} of the rays hit"
     if precision == "f64":
         assert err.max() < 1e-8, f"max ray error {err.max()}"
         assert np.array_equal(col_gpu, col_ref)
         np.testing.assert_allclose(obs, obs_ref, atol=1e-6)
     else:
-        # float32: hit/miss flips only at grazing incidence, everything else to 2e-4 m (8e-6 of max_dist), p99 5e-5
-        flips = (d_ref < md) != (d_gpu < md)
-        assert flips.mean() < 2e-3, f"{flips.sum()} hit/miss flips in {flips.size} rays"
-        both = (d_ref < md) & (d_gpu < md)
-        assert np.percentile(err[both], 99) < 5e-5
-        assert (err[both] > 2e-4).mean() < 2e-3
+        # float32, statistics over the rays that HIT (misses are exact by construction): hit/miss flips only at
+        # grazing incidence, p99 of the hit distances 5e-5 m, < 0.2 % of the hits off by more than 2e-4 m
+        flips = hit_ref != hit_gpu
+        assert flips.sum() <= 2e-3 * hit_ref.sum(), f"{flips.sum()} hit/miss flips among {hit_ref.sum()} hits"
+        both = hit_ref & hit_gpu
+        assert both.sum() > 0.15 * d_ref.size
+        assert np.percentile(err[both], 99) < 5e-5, np.percentile(err[both], 99)
+        assert (err[both] > 2e-4).mean() < 2e-3, (err[both] > 2e-4).mean()
         assert (col_gpu != col_ref).sum() <= 1
         ok = ~(err > 2e-4).any(axis=1) & (col_gpu == col_ref)
         np.testing.assert_allclose(obs[ok], obs_ref[ok], atol=2e-5)

@@ -326,6 +326,9 @@ def test_g7_trajectory_free_running(name):
             assert len(env.capsules) == n
             for c, ref in zip(env.capsules, g["ep_capsules"][e][:n]):
                 np.testing.assert_allclose(np.concatenate([c[0], c[1], [c[2]]]), ref, atol=1e-12)
+            if g["ep_sph_radii"].shape[1] > 0:    # SphereDocking3d: the oracle's own obstacle-field generator
+                np.testing.assert_allclose(env.sphere_centers, g["ep_sph_centers"][e], atol=1e-12)
+                np.testing.assert_allclose(env.sphere_radii, g["ep_sph_radii"][e], atol=1e-12)
         obs, rew, done, _ = env.step(g["action"][t])
         ctx = f"{name} t={t}"
         np.testing.assert_allclose(env.state, g["state"][t], rtol=1e-9, atol=1e-9, err_msg=ctx)
