@@ -187,6 +187,8 @@ void fill_env(EnvP<T>& e, const dockauv_env_s& h) {
     int pad = 1;
     while (pad < h.n_rays) pad *= 2;
     e.ray_pad = pad;
+    e.ray_pad_log2 = 0;
+    while ((1 << e.ray_pad_log2) < pad) ++e.ray_pad_log2;
     e.fan_cos = (T)h.fan_cos;
     e.fan_sin = (T)h.fan_sin;
     e.sum_beta = (T)h.sum_beta;
@@ -437,6 +439,38 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
         }
     }
     B.rays = rays_dev;
+    {
+        // lane table of the lane = ray stage (dockauv_device.h: Buffers::lane_tab)
+        void* lt_dev = nullptr;
+        int32_t* lc_dev = nullptr;
+        ALLOC(lt_dev, (size_t)64 * 4 * t);
+        ALLOC(lc_dev, (size_t)64 * 4);
+        if (h->n_rays <= 64) {
+            int pad = 1;
+            while (pad < h->n_rays) pad *= 2;
+            const int blk_ = c.blocksize_reduce, n_hr = (c.n_h + blk_ - 1) / blk_;
+            std::vector<unsigned char> tmp((size_t)64 * 4 * t);
+            int32_t cells[64];
+            for (int l = 0; l < 64; ++l) {
+                const int r = l % pad;
+                const bool ok = r < h->n_rays;
+                const double dir[4] = {ok ? c.ray_table[r * 4 + 0] : 1.0, ok ? c.ray_table[r * 4 + 1] : 0.0,
+                                       ok ? c.ray_table[r * 4 + 2] : 0.0, ok ? c.ray_table[r * 4 + 3] : 0.0};
+                for (int k = 0; k < 4; ++k) store_elem(h, 0, tmp.data(), (size_t)l * 4 + k, dir[k]);
+                const int iv = ok ? r / c.n_h : 0, ih = ok ? r % c.n_h : 0;
+                cells[l] = (iv / blk_) * n_hr + ih / blk_;
+            }
+            e = hipMemcpy(lt_dev, tmp.data(), tmp.size(), hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(lc_dev, cells, sizeof cells, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                fail(nullptr, DOCKAUV_E_HIP, "lane table upload: %s", hipGetErrorString(e));
+                dockauv_destroy(h);
+                return DOCKAUV_E_HIP;
+            }
+        }
+        B.lane_tab = lt_dev;
+        B.lane_cell = lc_dev;
+    }
     // host-pointer staging buffers
     const size_t N = (size_t)c.n_envs;
     ALLOC(h->d_actions, N * h->n_u_max * t);

@@ -56,7 +56,7 @@ struct EnvP {
     // ray stage with one lane per ray (fans of <= 64 rays): lanes per env (power of two >= n_rays), the circular cone
     // that contains the fan (cos / sin of its half-angle, widened by 1e-3 rad), the sum of the obstacle-avoidance
     // weights over all rays
-    int ray_pad;
+    int ray_pad, ray_pad_log2;
     T fan_cos, fan_sin, sum_beta;
 };
 
@@ -81,6 +81,11 @@ struct Buffers {
     void* p_sph;      // T [max_sph][4][S]
     // ray table: T [n_rays][4] = body-frame unit direction xyz, obstacle-avoidance weight beta_oa
     const void* rays;
+    // fans of <= 64 rays, lane = ray: what lane l of a wave needs to know about its ray r = l % ray_pad (unit direction
+    // (1, 0, 0) and weight 0 for the padding lanes r >= n_rays): T [64][4] = direction xyz, beta_oa; int32 [64] =
+    // block-max cell of the ray (sensor.py:131-137)
+    const void* lane_tab;
+    const int32_t* lane_cell;
     long stride;
 };
 

@@ -15,11 +15,12 @@
 #define REP64(x) REP16(x) REP16(x) REP16(x) REP16(x)
 
 enum { T_FMA_IND = 0, T_FMA_DEP, T_PKFMA_IND, T_PKFMA_DEP, T_MOV_DPP, T_FMAC_DPP, T_SIN, T_RCP, T_MIX_SALU, T_DSREAD_DEP,
-       T_FMA_SGPR2, T_PKMUL_IND, T_COUNT };
+       T_FMA_SGPR2, T_PKMUL_IND, T_FMA_HALF, T_FMA_QUARTER, T_COUNT };
 static const char* kNames[T_COUNT] = {"v_fma_f32 x8 independent", "v_fma_f32 dependent chain", "v_pk_fma_f32 x8 independent",
                                       "v_pk_fma_f32 dependent chain", "v_mov_b32_dpp quad_perm", "v_fmac_f32_dpp quad_perm",
                                       "v_sin_f32 independent", "v_rcp_f32 independent", "v_fma + s_add alternating",
-                                      "ds_read_b32 dependent chain", "v_fma_f32 (1 sgpr) + v_mov pair", "v_pk_mul_f32 x8 independent"};
+                                      "ds_read_b32 dependent chain", "v_fma_f32 (1 sgpr) + v_mov pair", "v_pk_mul_f32 x8 independent",
+                                      "v_fma_f32 dep, lanes 0-31 only", "v_fma_f32 dep, lanes 0-15 only"};
 
 template <int TEST>
 __global__ void k(unsigned long long* out, float* sink, float seed) {
@@ -70,6 +71,10 @@ __global__ void k(unsigned long long* out, float* sink, float seed) {
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0) : "v"(b), "v"(c));
         } else if (TEST == T_DSREAD_DEP) {
             asm volatile(REP64("ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)\n") : "+v"(addr));
+        } else if (TEST == T_FMA_HALF) {
+            if (threadIdx.x % 64 < 32) asm volatile(REP64("v_fma_f32 %0, %0, %1, %2\n") : "+v"(a0) : "v"(b), "v"(c));
+        } else if (TEST == T_FMA_QUARTER) {
+            if (threadIdx.x % 64 < 16) asm volatile(REP64("v_fma_f32 %0, %0, %1, %2\n") : "+v"(a0) : "v"(b), "v"(c));
         } else if (TEST == T_FMA_SGPR2) {
             // the constant bus takes one SGPR per VALU instruction on gfx9: a second scalar operand costs a v_mov
             asm volatile(REP16("v_mov_b32 %2, %4\n v_fma_f32 %0, %0, %5, %2\n v_mov_b32 %3, %4\n v_fma_f32 %1, %1, %5, %3\n")
@@ -112,7 +117,8 @@ static void run(unsigned long long* d_out, float* d_sink, double res[4]) {
             hipMemcpy(h, d_out, sizeof h, hipMemcpyDeviceToHost);
             double mx = 0;
             for (int w = 0; w < sizes[s] / 64; ++w) mx = std::max(mx, (double)h[w]);
-            v.push_back(mx / (32.0 * 64.0));
+            const double n_inst = (TEST == T_FMA_IND || TEST == T_PKFMA_IND || TEST == T_PKMUL_IND) ? 128.0 : 64.0;
+            v.push_back(mx / (32.0 * n_inst));
         }
         std::sort(v.begin(), v.end());
         res[s] = v[3];
@@ -130,7 +136,7 @@ int main() {
     double r[4];
 #define RUN(T) run<T>(d_out, d_sink, r); printf("%-36s %10.2f %10.2f %10.2f %10.2f\n", kNames[T], r[0], r[1], r[2], r[3]); fflush(stdout);
     RUN(T_FMA_IND) RUN(T_FMA_DEP) RUN(T_PKFMA_IND) RUN(T_PKFMA_DEP) RUN(T_PKMUL_IND) RUN(T_MOV_DPP) RUN(T_FMAC_DPP) RUN(T_SIN) RUN(T_RCP)
-    RUN(T_MIX_SALU) RUN(T_DSREAD_DEP) RUN(T_FMA_SGPR2)
+    RUN(T_FMA_HALF) RUN(T_FMA_QUARTER) RUN(T_DSREAD_DEP) RUN(T_FMA_SGPR2)
     uint32_t* tab;
     hipMalloc(&tab, 1 << 20);
     hipMemset(tab, 0, 1 << 20);

@@ -64,9 +64,20 @@ for i, nm in wave0:
     print(f"    {nm:<34s} at {v:8.0f}   (+{v - prev:6.0f})")
     prev = v
 print("  second wave of the group:")
-for i, nm in ((10, "ray stage entered / hand-over received"), (11, "first cell done / reward done"), (12, "all cells done / tail waves done"), (13, "barrier after the ray stage passed")):
+for i, nm in ((10, "ray stage entered / hand-over received"), (22, "active list built, free envs written"), (23, "ray passes done"), (11, "first cell done / reward done"), (12, "all cells done / tail waves done"), (13, "barrier after the ray stage passed")):
     v = med(i)
     if not np.isnan(v):
         print(f"    {nm:<42s} at {v:8.0f}")
+arr = [med(24 + w) for w in range(8)]
+if not all(np.isnan(a) for a in arr):
+    print("  arrival of (physical) waves 0.. at the barrier behind the ray stage: " + "  ".join("-" if np.isnan(a) else f"{a:.0f}" for a in arr))
+tt = total[:, :, 0]
+print(f"  group life (start -> end): median {np.nanmedian(tt):.0f}  p90 {np.nanpercentile(tt, 90):.0f}  p99 {np.nanpercentile(tt, 99):.0f}  max {np.nanmax(tt):.0f}; "
+      f"per launch, the slowest of the {G} sampled groups: median {np.nanmedian(np.nanmax(tt, axis=1)):.0f}")
+# the slowest sampled group of each launch: where did it spend the extra time?
+worst = np.nanargmax(tt, axis=1)
+sel = rel[np.arange(rel.shape[0]), worst]          # [launch, stamp]
+print("  slowest sampled group of each launch, medians: " + "  ".join(f"{nm.split()[0]}@{np.nanmedian(sel[:, i]):.0f}" for i, nm in
+      ((2, "landed"), (3, "rk"), (14, "publish"), (15, "records"), (4, "raydone"), (5, "navobs"), (8, "wb"), (9, "end")) if not np.all(np.isnan(sel[:, i]))))
 print(f"  total {np.nanmedian(total):.0f} ticks; group start spread within a launch {np.median(st[:, :, 0].max(axis=1) - st[:, :, 0].min(axis=1)):.0f}")
 env.close()
