@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdockauv.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_U = 8
 N_REWARDS = 13
 N_CONDITIONS = 5
@@ -23,7 +23,8 @@ F32, F64 = 0, 1
 VEH_CONSTB, VEH_LAUV = 0, 1
 RESET_NONE, RESET_POOL, RESET_DEVICE = 0, 1, 2
 
-(F_STATE, F_U, F_GOAL, F_CURRENT, F_TSTEPS, F_CAPSULES, F_SPHERES, F_VEHICLE_ID, F_CUM_REWARD, F_EPISODE) = range(10)
+(F_STATE, F_U, F_GOAL, F_CURRENT, F_TSTEPS, F_CAPSULES, F_SPHERES, F_VEHICLE_ID, F_CUM_REWARD, F_EPISODE,
+ F_CURRENT_SIGMA) = range(11)
 (F_POOL_POSE, F_POOL_GOAL, F_POOL_CURRENT, F_POOL_CAPSULES, F_POOL_SPHERES) = range(16, 21)
 
 SCN = {"SimpleDocking3d": 0, "SimpleCurrentDocking3d": 1, "CapsuleDocking3d": 2, "CapsuleCurrentDocking3d": 3,
@@ -65,6 +66,7 @@ class Config(C.Structure):
         ("radar_max_dist", C.c_double), ("radar_alpha_max", C.c_double), ("radar_beta_max", C.c_double),
         ("ray_table", C.POINTER(C.c_double)),
         ("vehicle", Vehicle * 2),
+        ("device_noise", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -72,7 +74,7 @@ class StepIO(C.Structure):
     _fields_ = [
         ("actions", C.c_void_p), ("noise", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p),
         ("done", C.c_void_p), ("reward_terms", C.c_void_p), ("conditions", C.c_void_p), ("nav", C.c_void_p),
-        ("ray_dist", C.c_void_p), ("terminal_obs", C.c_void_p),
+        ("ray_dist", C.c_void_p), ("terminal_obs", C.c_void_p), ("state_dot", C.c_void_p),
         ("pack_reward_done", C.c_int32), ("reserved", C.c_int32),
     ]
 
@@ -108,6 +110,9 @@ SYMBOLS = [
     ("dockauv_step_sequence", C.c_int, [C.c_void_p, C.POINTER(StepIO), C.c_int, C.c_void_p]),
     ("dockauv_step_host", C.c_int, [C.c_void_p, C.POINTER(StepIO)]),
     ("dockauv_synchronize", C.c_int, [C.c_void_p]),
+    ("dockauv_trace_enable", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    ("dockauv_trace_steps", C.c_longlong, [C.c_void_p]),
+    ("dockauv_trace_read", C.c_int, [C.c_void_p, C.c_longlong, C.c_int] + [C.c_void_p] * 8),
     ("dockauv_time_steps", C.c_int, [C.c_void_p, C.POINTER(StepIO), C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     ("dockauv_p2p_alloc", C.c_int, [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.c_char_p]),
     ("dockauv_p2p_free", C.c_int, [C.c_void_p]),

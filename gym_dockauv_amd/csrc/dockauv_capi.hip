@@ -58,11 +58,12 @@ struct dockauv_env_s {
     void* d_nav = nullptr;
     void* d_raydist = nullptr;
     float* d_termobs = nullptr;
+    void* d_statedot = nullptr;
     // pinned host mirrors of the above (dockauv_step_host), allocated on first use
     struct Pinned {
         void* actions = nullptr; void* noise = nullptr; float* obs = nullptr; void* reward = nullptr;
         uint8_t* done = nullptr; void* terms = nullptr; uint8_t* cond = nullptr; void* nav = nullptr;
-        void* raydist = nullptr; float* termobs = nullptr;
+        void* raydist = nullptr; float* termobs = nullptr; void* statedot = nullptr;
         bool ready = false;
     } pin;
     std::vector<void*> pinned_allocs;
@@ -71,6 +72,11 @@ struct dockauv_env_s {
     std::vector<unsigned char> ride_plans_host;
     hipEvent_t ev_step[2] = {nullptr, nullptr};     // dockauv_step_gather_sequence: step kernel / gather of row buffer k
     hipEvent_t ev_gather[2] = {nullptr, nullptr};
+    // episode-storage trace (dockauv_trace_*): ring buffers + their device-side description
+    TraceDev trace{};
+    void* trace_dev = nullptr;                      // device copy of `trace`
+    std::vector<void*> trace_allocs;
+    long long trace_step = 0;
 };
 
 namespace {
@@ -189,6 +195,7 @@ void fill_env(EnvP<T>& e, const dockauv_env_s& h) {
     e.ray_pad = pad;
     e.ray_pad_log2 = 0;
     while ((1 << e.ray_pad_log2) < pad) ++e.ray_pad_log2;
+    e.device_noise = c.device_noise ? 1 : 0;
     e.fan_cos = (T)h.fan_cos;
     e.fan_sin = (T)h.fan_sin;
     e.sum_beta = (T)h.sum_beta;
@@ -229,6 +236,7 @@ int field_info(dockauv_handle h, int field, FieldDesc* fd, int* width) {
         case DOCKAUV_F_VEHICLE_ID: *fd = {h->B.veh_id, 1, 2}; *width = 1; return 0;
         case DOCKAUV_F_CUM_REWARD: *fd = {h->B.cum_reward, 1, 0}; *width = 1; return 0;
         case DOCKAUV_F_EPISODE: *fd = {h->B.episode, 1, 1}; *width = 1; return 0;
+        case DOCKAUV_F_CURRENT_SIGMA: *fd = {h->B.cur_sigma, 1, 0}; *width = 1; return 0;
         case DOCKAUV_F_POOL_POSE: *fd = {h->B.p_pose, 6, 0}; *width = 6; return 0;
         case DOCKAUV_F_POOL_GOAL: *fd = {h->B.p_goal, 4, 0}; *width = 4; return 0;
         case DOCKAUV_F_POOL_CURRENT: *fd = {h->B.p_cur, 8, 0}; *width = 5; return 0;
@@ -269,11 +277,16 @@ void set_io(StepIO& d, const dockauv_step_io& s) {
     d.nav = s.nav;
     d.ray_dist = s.ray_dist;
     d.terminal_obs = s.terminal_obs;
+    d.state_dot = s.state_dot;
     d.pack = s.pack_reward_done ? 1 : 0;
 }
 
 int launch(dockauv_handle h, const dockauv_step_io* io, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     int rc;
+    StepIO& sio = h->f64 ? h->a64.io : h->a32.io;
+    sio.trace = h->trace_dev;
+    sio.trace_step = h->trace_dev ? h->trace_step++ : 0;
+    sio.device_noise = (h->cfg.device_noise && !io->noise) ? 1 : 0;
     if (h->f64) {
         set_io(h->a64.io, *io);
         rc = launch_step_f64(h->a64, h->vk, h->sym, h->has_rays, h->threads, stream, ev0, ev1);
@@ -293,7 +306,7 @@ extern "C" {
 int dockauv_abi_version(void) { return DOCKAUV_ABI_VERSION; }
 
 const char* dockauv_build_info(void) {
-    return "libdockauv gfx950 (HIP), abi " "1" ", built " __DATE__ " " __TIME__;
+    return "libdockauv gfx950 (HIP), abi " "2" ", built " __DATE__ " " __TIME__;
 }
 
 const char* dockauv_last_error(dockauv_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -419,6 +432,7 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
     ALLOC(B.t_steps, S * 4);
     ALLOC(B.episode, S * 4);
     ALLOC(B.veh_id, S);
+    ALLOC(B.cur_sigma, S * t);
     ALLOC(B.caps, (size_t)c.max_capsules * 7 * S * t);
     ALLOC(B.sph, (size_t)c.max_spheres * 4 * S * t);
     ALLOC(B.p_pose, 6 * S * t);
@@ -483,6 +497,7 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
     ALLOC(h->d_nav, N * 4 * t);
     ALLOC(h->d_raydist, N * h->n_rays * t);
     ALLOC(h->d_termobs, N * h->n_obs * 4);
+    ALLOC(h->d_statedot, N * 12 * t);
 #undef ALLOC
 
     if (h->f64) {
@@ -532,6 +547,8 @@ int dockauv_destroy(dockauv_handle h) {
     for (void* p : h->pinned_allocs) (void)hipHostFree(p);
     if (h->host_stream) (void)hipStreamDestroy(h->host_stream);
     if (h->ride_plans_dev) (void)hipFree(h->ride_plans_dev);
+    for (void* p : h->trace_allocs) (void)hipFree(p);
+    if (h->trace_dev) (void)hipFree(h->trace_dev);
     for (int k = 0; k < 2; ++k) {
         if (h->ev_step[k]) (void)hipEventDestroy(h->ev_step[k]);
         if (h->ev_gather[k]) (void)hipEventDestroy(h->ev_gather[k]);
@@ -762,6 +779,7 @@ int ensure_pinned(dockauv_handle h) {
     if ((rc = pinned_alloc(h, &h->pin.nav, N * 4 * t))) return rc;
     if ((rc = pinned_alloc(h, &h->pin.raydist, N * h->n_rays * t))) return rc;
     if ((rc = pinned_alloc(h, (void**)&h->pin.termobs, N * h->n_obs * 4))) return rc;
+    if ((rc = pinned_alloc(h, &h->pin.statedot, N * 12 * t))) return rc;
     HIP_TRY(h, hipStreamCreate(&h->host_stream));   // blocking stream: ordered after the null-stream copies of set_field / reset_envs
     h->pin.ready = true;
     return 0;
@@ -798,6 +816,7 @@ int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io) {
     d.nav = io->nav ? h->d_nav : nullptr;
     d.ray_dist = io->ray_dist ? h->d_raydist : nullptr;
     d.terminal_obs = io->terminal_obs ? h->d_termobs : nullptr;
+    d.state_dot = io->state_dot ? h->d_statedot : nullptr;
     rc = launch(h, &d, s);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(h->pin.obs, h->d_obs, N * h->n_obs * 4, hipMemcpyDeviceToHost, s));
@@ -807,6 +826,7 @@ int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io) {
     if (io->conditions) HIP_TRY(h, hipMemcpyAsync(h->pin.cond, h->d_cond, N, hipMemcpyDeviceToHost, s));
     if (io->nav) HIP_TRY(h, hipMemcpyAsync(h->pin.nav, h->d_nav, N * 4 * t, hipMemcpyDeviceToHost, s));
     if (io->ray_dist) HIP_TRY(h, hipMemcpyAsync(h->pin.raydist, h->d_raydist, N * h->n_rays * t, hipMemcpyDeviceToHost, s));
+    if (io->state_dot) HIP_TRY(h, hipMemcpyAsync(h->pin.statedot, h->d_statedot, N * 12 * t, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     if (io->terminal_obs) {
         // terminal observations only exist for envs that finished in this step: fetch the rows of those envs only
@@ -845,6 +865,101 @@ int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io) {
     if (io->conditions) std::memcpy(io->conditions, h->pin.cond, N);
     if (io->nav) std::memcpy(io->nav, h->pin.nav, N * 4 * t);
     if (io->ray_dist) std::memcpy(io->ray_dist, h->pin.raydist, N * h->n_rays * t);
+    if (io->state_dot) std::memcpy(io->state_dot, h->pin.statedot, N * 12 * t);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- episode-storage trace
+namespace {
+void trace_free(dockauv_handle h) {
+    for (void* p : h->trace_allocs) (void)hipFree(p);
+    h->trace_allocs.clear();
+    if (h->trace_dev) (void)hipFree(h->trace_dev);
+    h->trace_dev = nullptr;
+    h->trace = TraceDev{};
+    h->trace_step = 0;
+}
+}  // namespace
+
+int dockauv_trace_enable(dockauv_handle h, const int32_t* env_ids, int n_rows, int capacity) {
+    if (!h) return DOCKAUV_E_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream)); else HIP_TRY(h, hipDeviceSynchronize());
+    trace_free(h);
+    if (n_rows == 0) return 0;
+    if (!env_ids || n_rows < 0 || capacity < 1) return fail(h, DOCKAUV_E_INVALID, "bad trace arguments");
+    const int N = h->cfg.n_envs;
+    std::vector<int32_t> slot((size_t)N, -1);
+    for (int j = 0; j < n_rows; ++j) {
+        if (env_ids[j] < 0 || env_ids[j] >= N || (j > 0 && env_ids[j] <= env_ids[j - 1]))
+            return fail(h, DOCKAUV_E_RANGE, "trace env ids must be strictly increasing inside [0, %d)", N);
+        slot[(size_t)env_ids[j]] = j;
+    }
+    const size_t rows = (size_t)capacity * (size_t)n_rows, t = h->tsz;
+    auto alloc = [&](void** p, size_t bytes) -> int {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) return fail(h, DOCKAUV_E_HIP, "hipMalloc(%zu) for the trace failed: %s", bytes, hipGetErrorString(e));
+        h->trace_allocs.push_back(*p);
+        e = hipMemset(*p, 0, bytes);
+        return e == hipSuccess ? 0 : fail(h, DOCKAUV_E_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    };
+    TraceDev& tr = h->trace;
+    void* slot_dev = nullptr;
+    int rc = 0;
+    if ((rc = alloc(&slot_dev, (size_t)N * 4)) || (rc = alloc(&tr.state_pre, rows * 12 * t)) || (rc = alloc(&tr.state, rows * 12 * t)) ||
+        (rc = alloc(&tr.state_dot, rows * 12 * t)) || (rc = alloc(&tr.u, rows * kMaxU * t)) || (rc = alloc(&tr.nu_c, rows * 3 * t)) ||
+        (rc = alloc((void**)&tr.obs, rows * (size_t)h->n_obs * 4)) || (rc = alloc(&tr.reward_terms, rows * kNRew * t)) ||
+        (rc = alloc((void**)&tr.cond, rows))) {
+        trace_free(h);
+        return rc;
+    }
+    tr.slot_of_env = static_cast<const int32_t*>(slot_dev);
+    tr.n_rows = n_rows;
+    tr.capacity = capacity;
+    hipError_t e = hipMemcpy(slot_dev, slot.data(), (size_t)N * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&h->trace_dev, sizeof(TraceDev));
+    if (e == hipSuccess) e = hipMemcpy(h->trace_dev, &tr, sizeof(TraceDev), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        trace_free(h);
+        return fail(h, DOCKAUV_E_HIP, "trace set-up failed: %s", hipGetErrorString(e));
+    }
+    h->trace_step = 0;
+    return 0;
+}
+
+long long dockauv_trace_steps(dockauv_handle h) { return h ? h->trace_step : (long long)DOCKAUV_E_INVALID; }
+
+int dockauv_trace_read(dockauv_handle h, long long first_step, int n_steps, double* state_pre, double* state, double* state_dot,
+                       double* u, double* nu_c, float* obs, double* reward_terms, uint8_t* conditions) {
+    if (!h || !h->trace_dev) return fail(h, DOCKAUV_E_INVALID, "trace is not enabled");
+    const TraceDev& tr = h->trace;
+    if (n_steps < 0 || first_step < 0 || first_step + n_steps > h->trace_step || h->trace_step - first_step > tr.capacity)
+        return fail(h, DOCKAUV_E_RANGE, "steps [%lld, %lld) are not in the ring (recorded %lld, capacity %d)", first_step,
+                    first_step + n_steps, h->trace_step, tr.capacity);
+    if (n_steps == 0) return 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream)); else HIP_TRY(h, hipDeviceSynchronize());
+    const size_t R = (size_t)tr.n_rows;
+    std::vector<unsigned char> tmp;
+    // one ring array -> host [n_steps][n_rows][w]; kind 0 = T -> double, 1 = float, 2 = uint8
+    auto fetch = [&](const void* dev, int w, int kind, void* out) -> int {
+        if (!out) return 0;
+        const size_t es = kind == 0 ? h->tsz : (kind == 1 ? 4 : 1), row_bytes = R * (size_t)w * es;
+        tmp.resize(row_bytes * (size_t)n_steps);
+        for (int k = 0; k < n_steps; ++k) {
+            const size_t slot = (size_t)((first_step + k) % tr.capacity);
+            HIP_TRY(h, hipMemcpy(tmp.data() + (size_t)k * row_bytes, static_cast<const unsigned char*>(dev) + slot * row_bytes, row_bytes, hipMemcpyDeviceToHost));
+        }
+        const size_t n = (size_t)n_steps * R * (size_t)w;
+        if (kind == 0) for (size_t i = 0; i < n; ++i) static_cast<double*>(out)[i] = load_elem(h, 0, tmp.data(), i);
+        else std::memcpy(out, tmp.data(), n * es);
+        return 0;
+    };
+    int rc;
+    if ((rc = fetch(tr.state_pre, 12, 0, state_pre)) || (rc = fetch(tr.state, 12, 0, state)) || (rc = fetch(tr.state_dot, 12, 0, state_dot)) ||
+        (rc = fetch(tr.u, kMaxU, 0, u)) || (rc = fetch(tr.nu_c, 3, 0, nu_c)) || (rc = fetch(tr.obs, h->n_obs, 1, obs)) ||
+        (rc = fetch(tr.reward_terms, kNRew, 0, reward_terms)) || (rc = fetch(tr.cond, 1, 2, conditions)))
+        return rc;
     return 0;
 }
 

@@ -57,6 +57,7 @@ struct EnvP {
     // that contains the fan (cos / sin of its half-angle, widened by 1e-3 rad), the sum of the obstacle-avoidance
     // weights over all rays
     int ray_pad, ray_pad_log2;
+    int device_noise;    // 1: the kernel draws the current's white noise itself (dockauv_config::device_noise)
     T fan_cos, fan_sin, sum_beta;
 };
 
@@ -71,6 +72,7 @@ struct Buffers {
     int32_t* t_steps; // [S]
     int32_t* episode; // [S]
     uint8_t* veh_id;  // [S]
+    void* cur_sigma;  // T [S]      white_noise_std of the env's current (device_noise)
     void* caps;       // T [max_cap][7][S]
     void* sph;        // T [max_sph][4][S]
     // next-episode pool (DOCKAUV_RESET_POOL)
@@ -100,7 +102,26 @@ struct StepIO {
     void* nav;
     void* ray_dist;
     float* terminal_obs;
+    void* state_dot;          // T [N][12] or null
+    const void* trace;        // TraceDev in device memory or null (library-owned, dockauv_trace_enable)
+    long long trace_step;     // index of this step in the trace
     int pack;
+    int device_noise;         // 1: no noise array given and the handle draws the current's white noise itself
+};
+
+// ring of the last `capacity` steps of `n_rows` selected envs (include/dockauv.h: dockauv_trace_*); row-major
+// [capacity][n_rows][width]
+struct TraceDev {
+    const int32_t* slot_of_env;   // [n_envs]: row of the env in the ring, -1 = not selected
+    int n_rows, capacity;
+    void* state_pre;      // T [..][12]
+    void* state;          // T [..][12]
+    void* state_dot;      // T [..][12]
+    void* u;              // T [..][kMaxU]
+    void* nu_c;           // T [..][3]
+    float* obs;           // [..][n_obs]
+    void* reward_terms;   // T [..][kNRew]
+    uint8_t* cond;        // [..]
 };
 
 // Vehicle / reward / fan parameters (~1.7 KB in f32).  They live in a DEVICE buffer that persists across launches

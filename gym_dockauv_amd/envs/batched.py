@@ -75,7 +75,8 @@ class BatchedDocking3d:
                  vehicles: Optional[Sequence[str]] = None, max_capsules: Optional[int] = None,
                  max_spheres: Optional[int] = None, threads_per_group: int = 0,
                  vehicle_models: Optional[Sequence[VehicleModel]] = None, current_mu: float = scenarios.CURRENT_MU,
-                 reset_mode: Optional[str] = None, device_seed: int = 0, _force_general: bool = False):
+                 reset_mode: Optional[str] = None, device_seed: int = 0, _force_general: bool = False,
+                 device_noise: bool = False):
         if scenario not in scenarios.SCENARIOS:
             raise KeyError(f"Not valid scenario, available options are {scenarios.SCENARIOS}")
         self.config = copy.deepcopy(env_config)
@@ -91,6 +92,9 @@ class BatchedDocking3d:
             raise ValueError("reset_mode must be 'none', 'pool' or 'device'")
         self.reset_mode = reset_mode
         self.device_seed = int(device_seed)
+        # device_noise: the kernel draws the white noise of each env's Gauss-Markov current itself (sigma per env:
+        # F_CURRENT_SIGMA, objects/current.py:31,88) whenever step() is not given a noise array
+        self.device_noise = bool(device_noise)
         self._force_general = bool(_force_general)   # test hook: general kinetics expressions
         self.auto_reset = reset_mode != "none"
         self.rng_mode = rng
@@ -168,6 +172,8 @@ class BatchedDocking3d:
         self._nav = np.zeros((N, 4), dtype=self._np_t)
         self._ray = np.zeros((N, self.radar.n_rays), dtype=self._np_t)
         self._termobs = np.zeros((N, self.n_observations), dtype=np.float32)
+        self._statedot = np.zeros((N, 12), dtype=self._np_t)
+        self.episode_storage = None          # BatchEpisodeStorage (enable_episode_storage)
 
     # ------------------------------------------------------------------------------------------ config
     def _build_config(self) -> _capi.Config:
@@ -207,6 +213,7 @@ class BatchedDocking3d:
         cfg.action_reward_factors[:] = w.tolist()
         cfg.radar_max_dist = self.radar.max_dist
         cfg.radar_alpha_max, cfg.radar_beta_max = self.radar.alpha_max, self.radar.beta_max
+        cfg.device_noise = 1 if self.device_noise else 0
         cfg.ray_table = self._ray_table.ctypes.data_as(C.POINTER(C.c_double))
         for i, m in enumerate(self.vehicle_models):
             cfg.vehicle[i] = m.to_capi()
@@ -388,6 +395,7 @@ class BatchedDocking3d:
             io.reward_terms = self._terms.ctypes.data
             io.nav = self._nav.ctypes.data
             io.ray_dist = self._ray.ctypes.data
+            io.state_dot = self._statedot.ctypes.data
         return io
 
     def step_async(self, actions: np.ndarray) -> None:
@@ -410,6 +418,8 @@ class BatchedDocking3d:
         self.t_total_steps += 1
         self._steps_since_reset += 1
         done = self._done.astype(bool)
+        if self.episode_storage is not None:
+            self.episode_storage.after_step(done)
         # VecEnv contract: one info mapping per env.  Envs that did not finish share ONE read-only empty mapping
         # (building 65 536 dicts per step costs more than the step); finished envs get their own dict.
         infos: List[dict] = [_NO_INFO] * self.num_envs
@@ -454,6 +464,46 @@ class BatchedDocking3d:
     @property
     def intersec_dist(self) -> np.ndarray:
         return self._ray
+
+    @property
+    def state_dot(self) -> np.ndarray:
+        """AUVSim._state_dot of the last step(extras=True) (objects/auvsim.py:108)."""
+        return self._statedot
+
+    # ------------------------------------------------------------------------------------------ episode storage
+    def enable_trace(self, env_ids: Sequence[int], capacity: int) -> None:
+        """Device ring of the last `capacity` steps of the selected envs (dockauv_trace_enable); [] switches it off."""
+        ids = np.ascontiguousarray(sorted(int(i) for i in env_ids), dtype=np.int32)
+        rc = self._lib.dockauv_trace_enable(self._handle, ids.ctypes.data_as(C.c_void_p), int(ids.size), int(capacity))
+        _capi.check(self._lib, self._handle, rc, "dockauv_trace_enable")
+        self._trace_ids = ids
+
+    def trace_steps(self) -> int:
+        return int(self._lib.dockauv_trace_steps(self._handle))
+
+    def read_trace(self, first_step: int, n_steps: int) -> Dict[str, np.ndarray]:
+        """Steps [first_step, first_step + n_steps) of the ring as host arrays [n_steps][n_rows][width]."""
+        R = int(self._trace_ids.size)
+        out = {"state_pre": np.zeros((n_steps, R, 12)), "state": np.zeros((n_steps, R, 12)),
+               "state_dot": np.zeros((n_steps, R, 12)), "u": np.zeros((n_steps, R, _capi.MAX_U)),
+               "nu_c": np.zeros((n_steps, R, 3)), "obs": np.zeros((n_steps, R, self.n_observations), dtype=np.float32),
+               "reward_terms": np.zeros((n_steps, R, 13)), "conditions": np.zeros((n_steps, R), dtype=np.uint8)}
+        rc = self._lib.dockauv_trace_read(self._handle, int(first_step), int(n_steps),
+                                          *[out[k].ctypes.data_as(C.c_void_p) for k in
+                                            ("state_pre", "state", "state_dot", "u", "nu_c", "obs", "reward_terms", "conditions")])
+        _capi.check(self._lib, self._handle, rc, "dockauv_trace_read")
+        return out
+
+    def enable_episode_storage(self, env_ids: Sequence[int], path_folder: str, title: str = "", capacity: Optional[int] = None):
+        """EpisodeDataStorage (utils/datastorage.py:164-343) for selected envs of the batch: the step kernel records
+        their per-step arrays in a device ring; every finished episode of a selected env is written as one pickle
+        with the reference's schema (docking3d.py:252-259).  Works for the host path (flushed by step()) and for
+        device-resident rollouts (call env.episode_storage.flush() at least every `capacity` steps)."""
+        from ..utils.datastorage import BatchEpisodeStorage
+        cap = int(capacity or (int(self.config["max_timesteps"]) + 2))
+        self.enable_trace(env_ids, cap)
+        self.episode_storage = BatchEpisodeStorage(self, path_folder, title, cap)
+        return self.episode_storage
 
     # ------------------------------------------------------------------------------------------ device-pointer path
     def step_device(self, actions_ptr: int, obs_ptr: int, reward_ptr: int = 0, done_ptr: int = 0, stream: int = 0,

@@ -70,6 +70,17 @@ class _AUVView:
     def u(self) -> np.ndarray:
         return self._env._batch.u[0]
 
+    @property
+    def state_dot(self) -> np.ndarray:
+        """AUVSim._state_dot (objects/auvsim.py:62,108): zeros after reset, else the RHS at the new state."""
+        return np.zeros(12) if self._env.t_steps == 0 else np.asarray(self._env._batch.state_dot[0], dtype=np.float64).copy()
+
+    _state_dot = state_dot
+
+    @property
+    def euler_dot(self) -> np.ndarray:
+        return self.state_dot[3:6]
+
 
 class _RadarView:
     """``env.radar``: layout constants plus the last intersection distances / end points (objects/sensor.py:104-129)."""

@@ -13,8 +13,12 @@ the reference's Python objects and are plain data instead:
 * ``storage["shapes"]``: dicts ``{"type": "Capsule", "position", "vec_bot", "vec_top", "radius"}`` /
   ``{"type": "Sphere", "position", "radius"}`` instead of ``Shape`` instances (their plot meshes are rendering code);
 
-and ``storage["vehicle"]["states_dot"]`` is NaN: the kernel evaluates of the post-step right-hand side only what the
-reward needs (the Euler-angle rates).
+``storage["vehicle"]["states_dot"]`` is AUVSim._state_dot (objects/auvsim.py:108), which the kernel evaluates in full
+when a caller asks for it (dockauv_step_io.state_dot).
+
+``BatchEpisodeStorage`` is the same storage for SELECTED ENVS OF A BATCH: the step kernel keeps their per-step arrays in
+a device ring (include/dockauv.h: dockauv_trace_*), so that device-resident rollouts are logged without a host round
+trip per step; every finished episode becomes one pickle of the schema above.
 """
 from __future__ import annotations
 
@@ -27,31 +31,36 @@ import numpy as np
 
 
 class ArrayList:
-    """Growable n x c array (reference: utils/datastorage.py:120-161): first row = the initial vector."""
+    """Rows appended one at a time; the first row is the initial vector (what the reference's storages keep,
+    utils/datastorage.py:120-161).  Rows are collected in a Python list of blocks and joined on demand."""
+
+    _BLOCK = 256
 
     def __init__(self, init_array):
-        init_array = np.asarray(init_array, dtype=float)
-        self.dim_col = init_array.shape
-        self.capacity = 100
-        self.array_grow_factor = 4
-        self.data = np.zeros((self.capacity, *self.dim_col))
-        self.size = 1
-        self.data[0] = init_array
+        first = np.array(init_array, dtype=float)
+        self._shape = first.shape
+        self._blocks = []
+        self._cur = np.empty((self._BLOCK, *self._shape))
+        self._n = 0
+        self.add_row(first)
 
-    def __getitem__(self, index):
-        return self.data[:self.size][index]
+    @property
+    def size(self) -> int:
+        return len(self._blocks) * self._BLOCK + self._n
 
     def add_row(self, row) -> None:
-        if self.size == self.capacity:
-            self.capacity *= self.array_grow_factor
-            grown = np.zeros((self.capacity, *self.dim_col))
-            grown[:self.size] = self.data
-            self.data = grown
-        self.data[self.size] = row
-        self.size += 1
+        if self._n == self._BLOCK:
+            self._blocks.append(self._cur)
+            self._cur = np.empty((self._BLOCK, *self._shape))
+            self._n = 0
+        self._cur[self._n] = row
+        self._n += 1
 
     def get_nparray(self) -> np.ndarray:
-        return self.data[:self.size]
+        return np.concatenate([*self._blocks, self._cur[:self._n]], axis=0)
+
+    def __getitem__(self, index):
+        return self.get_nparray()[index]
 
 
 def _stamp() -> str:
@@ -121,7 +130,7 @@ class EpisodeDataStorage:
                 "object": {"name": getattr(auv, "name", ""), "u_bound": np.asarray(auv.u_bound, dtype=float),
                            "safety_radius": float(auv.safety_radius)},
                 "states": ArrayList(state),
-                "states_dot": ArrayList(np.full(12, np.nan)),
+                "states_dot": ArrayList(np.zeros(12)),            # AUVSim.reset: _state_dot = 0 (auvsim.py:62)
                 "u": ArrayList(auv.u),
             },
             "radar": ArrayList(env.radar.end_pos_n),
@@ -143,7 +152,7 @@ class EpisodeDataStorage:
         auv = self.env.auv
         v = self.storage["vehicle"]
         v["states"].add_row(auv.state)
-        v["states_dot"].add_row(np.full(12, np.nan))
+        v["states_dot"].add_row(getattr(auv, "state_dot", np.full(12, np.nan)))
         v["u"].add_row(auv.u)
         self.storage["nu_c"].add_row(nu_c)
         self.storage["cum_rewards"].add_row(self.env.cum_reward_arr)
@@ -192,3 +201,98 @@ class EpisodeDataStorage:
     @property
     def nu_c(self) -> np.ndarray:
         return self.storage["nu_c"][:]
+
+
+class BatchEpisodeStorage:
+    """EpisodeDataStorage for selected envs of a BatchedDocking3d, fed from the device trace ring.
+
+    Row layout of a pickle (reference: utils/datastorage.py:254-271, 273-291): index 0 = the values at reset (state the
+    episode started from, zeros for state_dot / u / rewards / observation -- Q8: reset returns zeros), index k = after
+    step k.  ``nu_c`` rows are 6 wide (last three zero) as in the reference; row 0 repeats the first step's value (the
+    reset-time current differs from it by one Gauss-Markov update of V_c)."""
+
+    def __init__(self, env, path_folder: str, title: str, capacity: int):
+        self.env = env
+        self.path_folder = path_folder
+        self.title = title
+        self.capacity = int(capacity)
+        self.ids = np.array(env._trace_ids)
+        self._flushed = 0                                   # steps already looked at
+        self._open = {int(i): [] for i in self.ids}         # env id -> list of per-step dicts of the running episode
+        self._episode_no = {int(i): 1 for i in self.ids}
+        self.files = []
+        if len(path_folder) > 0:
+            os.makedirs(path_folder, exist_ok=True)
+
+    def after_step(self, done: np.ndarray) -> None:
+        """Host path: called by BatchedDocking3d.step; flushes when a selected env finished or the ring is half full."""
+        if done[self.ids].any() or self.env.trace_steps() - self._flushed >= self.capacity // 2:
+            self.flush()
+
+    def flush(self):
+        """Pull the steps recorded since the last flush from the device ring and write finished episodes."""
+        n_now = self.env.trace_steps()
+        n_new = n_now - self._flushed
+        if n_new <= 0:
+            return []
+        if n_new > self.capacity:
+            raise RuntimeError(f"trace ring overrun: {n_new} steps since the last flush, capacity {self.capacity}")
+        tr = self.env.read_trace(self._flushed, n_new)
+        self._flushed = n_now
+        written = []
+        for j, env_id in enumerate(self.ids.tolist()):
+            for k in range(n_new):
+                self._open[env_id].append({key: tr[key][k, j] for key in tr})
+                if tr["conditions"][k, j] != 0:
+                    written.append(self._save(env_id))
+        return written
+
+    def _save(self, env_id: int) -> str:
+        steps = self._open[env_id]
+        self._open[env_id] = []
+        env = self.env
+        n_u = int(env.vehicle_models[int(env.vehicle_id[env_id])].u_bound.shape[0])
+        n_obs = env.n_observations
+        T = len(steps)
+        states = np.zeros((T + 1, 12))
+        states_dot = np.zeros((T + 1, 12))
+        u = np.zeros((T + 1, n_u))
+        nu_c = np.zeros((T + 1, 6))
+        rewards = np.zeros((T + 1, 13))
+        obs = np.zeros((T + 1, n_obs))
+        states[0] = steps[0]["state_pre"]
+        for k, s in enumerate(steps):
+            states[k + 1] = s["state"]
+            states_dot[k + 1] = s["state_dot"]
+            u[k + 1] = s["u"][:n_u]
+            nu_c[k + 1, 0:3] = s["nu_c"]
+            rewards[k + 1] = s["reward_terms"]
+            obs[k + 1] = s["obs"]
+        nu_c[0] = nu_c[1]
+        episode = self._episode_no[env_id]
+        self._episode_no[env_id] += 1
+        model = env.vehicle_models[int(env.vehicle_id[env_id])]
+        storage = {
+            "vehicle": {"object": {"name": getattr(model, "name", ""), "u_bound": np.asarray(model.u_bound, dtype=float),
+                                   "safety_radius": float(model.safety_radius)},
+                        "states": states, "states_dot": states_dot, "u": u},
+            "radar": None,            # ray end points are a rendering input (plotutils); the distances are in the observation
+            "nu_c": nu_c,
+            "shapes": [],
+            "title": self.title,
+            "episode": episode,
+            "step_size": float(env.config["t_step_size"]),
+            "cum_rewards": np.cumsum(rewards, axis=0),
+            "rewards": rewards,
+            "meta_data_reward": env.meta_data_reward,
+            "n_cont_rewards": env.n_cont_rewards,
+            "observation": obs,
+            "meta_data_observation": None,
+            "env_index": env_id,
+            "conditions_last_step": int(steps[-1]["conditions"]),
+        }
+        name = os.path.join(self.path_folder, f"{_stamp()}__{self.title}__ENV_{env_id}__EPISODE_{episode}_DATA_STORAGE.pkl")
+        with open(name, "wb") as f:
+            pickle.dump(storage, f, pickle.HIGHEST_PROTOCOL)
+        self.files.append(name)
+        return name

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DOCKAUV_ABI_VERSION 1
+#define DOCKAUV_ABI_VERSION 2
 #define DOCKAUV_MAX_U 8          /* inputs: BlueROV2 joystick 6, BlueROV2 direct 8, LAUV 3 */
 #define DOCKAUV_N_REWARDS 13     /* envs/docking3d.py:152 */
 #define DOCKAUV_N_CONDITIONS 5   /* envs/docking3d.py:597-619 */
@@ -121,6 +121,13 @@ typedef struct dockauv_config {
      * (sensor.py:66-71) and the obstacle-avoidance weight beta_oa (docking3d.py:786-788).  Read during create only. */
     const double* ray_table;
     dockauv_vehicle vehicle[2];
+    /* Gauss-Markov current with sigma > 0 (objects/current.py:88, w = np.random.normal(0, sigma)) when the caller
+     * passes no noise array: 0 = w = 0 (what every shipped scenario has: white_noise_std = 0, docking3d.py:820);
+     * 1 = the kernel draws w = sigma_env * N(0, 1) itself -- Philox4x32-10 counter (env, episode, t_steps, 1), key =
+     * seed, Box-Muller on the first two words (oracle/philox_ref.py: philox_normal); sigma_env = field
+     * DOCKAUV_F_CURRENT_SIGMA.  dockauv_step_io.noise, when given, always wins (parity mode). */
+    int32_t device_noise;
+    int32_t reserved0;
 } dockauv_config;
 
 typedef struct dockauv_env_s* dockauv_handle;
@@ -136,6 +143,7 @@ typedef struct dockauv_env_s* dockauv_handle;
 #define DOCKAUV_F_VEHICLE_ID 7   /* 1: index into config.vehicle[] (mixed batches) */
 #define DOCKAUV_F_CUM_REWARD 8   /* 1: cumulative reward of the running episode (docking3d.py:156) */
 #define DOCKAUV_F_EPISODE 9      /* 1: episode counter (docking3d.py:141) */
+#define DOCKAUV_F_CURRENT_SIGMA 10 /* 1: white_noise_std of the env's current (objects/current.py:31); read by device_noise */
 /* next-episode pool (DOCKAUV_RESET_POOL): same layouts */
 #define DOCKAUV_F_POOL_POSE 16       /* 6: position, attitude */
 #define DOCKAUV_F_POOL_GOAL 17       /* 4 */
@@ -162,6 +170,9 @@ typedef struct dockauv_step_io {
     void* nav;               /* nullable, T [n_envs][4]: delta_d, delta_theta, delta_psi, delta_heading_goal */
     void* ray_dist;          /* nullable, T [n_envs][n_rays]: clamped intersec_dist (sensor.py:113-118) */
     float* terminal_obs;     /* nullable, float32 [n_envs][n_obs]: written only where done (auto-reset modes) */
+    void* state_dot;         /* nullable, T [n_envs][12]: AUVSim._state_dot, the right-hand side at the new state with the
+                                new input (objects/auvsim.py:108), what EpisodeDataStorage logs as "states_dot"
+                                (utils/datastorage.py:272,299) */
     int32_t pack_reward_done; /* 0/1, see obs */
     int32_t reserved;
 } dockauv_step_io;
@@ -202,6 +213,26 @@ int dockauv_step_sequence(dockauv_handle h, const dockauv_step_io* ios, int n, v
 int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io);
 /* block until everything queued on the handle's last-used stream is done */
 int dockauv_synchronize(dockauv_handle h);
+
+/*
+ * Episode storage for selected envs of a batch (utils/datastorage.py:164-343 EpisodeDataStorage, hooked at
+ * docking3d.py:252-259,363-364): a ring of the last `capacity` steps of `n_rows` chosen envs, kept in HBM and written
+ * by the step kernel itself, so that a device-resident rollout (no host round trip per step) can still hand the
+ * reference's per-step arrays to its post-analysis.  Per step and selected env the kernel records: the state the step
+ * started from, the new state, _state_dot, the filtered input u, nu_c (body frame, first three), the observation
+ * BEFORE any auto-reset zeroing, the 13 reward terms and the condition bits.  Row of step k: k % capacity.
+ * dockauv_trace_enable(h, env_ids, n_rows, capacity): env_ids host array, strictly increasing; n_rows = 0 switches
+ *   the trace off and frees the ring.  The step counter restarts at 0.
+ * dockauv_trace_steps(h): steps recorded since enable (or a negative error code).
+ * dockauv_trace_read(h, first_step, n_steps, ...): copies steps [first_step, first_step + n_steps) -- they must still be
+ *   in the ring -- to host arrays [n_steps][n_rows][width] (float64, obs float32, conditions uint8); any of the output
+ *   pointers may be NULL.  Synchronises with the handle's last-used stream.
+ */
+int dockauv_trace_enable(dockauv_handle h, const int32_t* env_ids, int n_rows, int capacity);
+long long dockauv_trace_steps(dockauv_handle h);
+int dockauv_trace_read(dockauv_handle h, long long first_step, int n_steps, double* state_pre /*12*/, double* state /*12*/,
+                       double* state_dot /*12*/, double* u /*DOCKAUV_MAX_U*/, double* nu_c /*3*/, float* obs /*n_obs*/,
+                       double* reward_terms /*13*/, uint8_t* conditions /*1*/);
 
 /* measurement helper (bench.py): run `steps` step launches back-to-back on `stream` re-using the same io, each
  * dispatch carrying its own start/stop HIP events ON THAT STREAM; returns the average KERNEL duration in microseconds

@@ -41,3 +41,18 @@ def episode_uniforms(seed: int, env: np.ndarray, episode: np.ndarray) -> np.ndar
         x = philox4x32_10(ctr, key)
         out.append((x >> np.uint32(8)).astype(np.float64) / 16777216.0)
     return np.concatenate(out, axis=-1)
+
+
+def philox_normal(seed: int, env: np.ndarray, episode: np.ndarray, t_steps: np.ndarray) -> np.ndarray:
+    """The standard normal the kernel draws for the current's white noise of (env, episode, step) when
+    dockauv_config.device_noise is set: counter = (env, episode, t_steps, 1), key = seed, Box-Muller on the first two
+    words with u1 = ((x0 >> 8) + 0.5) 2^-24 in (0, 1), u2 = (x1 >> 8) 2^-24:  z = sqrt(-2 ln u1) cos(2 pi u2)."""
+    env = np.asarray(env, dtype=np.uint64)
+    episode = np.broadcast_to(np.asarray(episode, dtype=np.uint64), env.shape)
+    t_steps = np.broadcast_to(np.asarray(t_steps, dtype=np.uint64), env.shape)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], dtype=np.uint64)
+    ctr = np.stack([env, episode, t_steps, np.ones_like(env)], axis=-1)
+    x = philox4x32_10(ctr, key)
+    u1 = ((x[..., 0] >> np.uint32(8)).astype(np.float64) + 0.5) / 16777216.0
+    u2 = (x[..., 1] >> np.uint32(8)).astype(np.float64) / 16777216.0
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)

@@ -222,3 +222,37 @@ def test_wave_layouts_agree(scenario, layouts):
                 np.testing.assert_allclose(z1, z2, rtol=0, atol=2e-6)
         np.testing.assert_allclose(outs[0][1], other[1], rtol=0, atol=5e-6)
         np.testing.assert_allclose(outs[0][2], other[2], rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_device_noise_matches_philox_reference(precision):
+    """dockauv_config.device_noise: the white noise of the Gauss-Markov current (objects/current.py:88) drawn in the
+    kernel -- V_c of every env over 30 steps against the host recurrence fed with oracle/philox_ref.py: philox_normal."""
+    from gym_dockauv_amd import _capi
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    from oracle import philox_ref
+    N, K, seed = 200, 30, 0xC0FFEE1234
+    env = BatchedDocking3d(num_envs=N, scenario="SimpleCurrentDocking3d", precision=precision, reset_mode="none",
+                           rng="batched", device_seed=seed, device_noise=True, current_mu=0.01)
+    try:
+        env._gen = np.random.default_rng(4)
+        env.reset()
+        rs = np.random.RandomState(1)
+        cur = env.get_field(_capi.F_CURRENT)
+        cur[:, 0], cur[:, 1], cur[:, 2] = 0.5, 0.2, 1.0          # V_c, V_min, V_max (tests/test_integration.py of the reference)
+        env.set_field(_capi.F_CURRENT, cur)
+        sigma = rs.uniform(0.0, 0.2, N)
+        sigma[::7] = 0.0
+        env.set_field(_capi.F_CURRENT_SIGMA, sigma[:, None])
+        episode = env.get_field(_capi.F_EPISODE)[:, 0].astype(np.int64)
+        h = float(env.config["t_step_size"])
+        vc = cur[:, 0].copy()
+        for t in range(K):
+            env.step(np.zeros((N, 6)))
+            z = philox_ref.philox_normal(seed, np.arange(N), episode, np.full(N, t))
+            vc = np.clip(vc + (-0.01 * vc + sigma * z) * h, 0.2, 1.0)
+            got = env.get_field(_capi.F_CURRENT)[:, 0]
+            np.testing.assert_allclose(got, vc, atol=1e-12 if precision == "f64" else 2e-6)
+        assert np.ptp(vc[sigma > 0.05]) > 0.01 and np.all(np.abs(vc[::7] - vc[0]) < 1e-9)
+    finally:
+        env.close()

@@ -1,0 +1,128 @@
+"""
+Episode storage for selected envs of a batch (reference utils/datastorage.py:164-343,
+hooks docking3d.py:252-259,363-364): a golden trajectory is replayed free-running on a few envs of a larger batch with
+the device trace ring on, and the pickles written at each episode end are compared with the fixture
+(states / u / observation / rewards from the reference's own outputs; states_dot rows 3:6 with the fixture's euler_dot,
+all twelve with the oracle, which tests/test_oracle_golden.py pins to the reference's state_dot vectors).
+"""
+import pickle
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,precision", [("traj_ObstaclesCurrentDocking3d_bluerov2_random", "f64"),
+                                            ("traj_ObstaclesCurrentDocking3d_bluerov2_random", "f32"),
+                                            ("traj_ObstaclesDocking3d_lauv_goto", "f64")])
+def test_batch_episode_storage_matches_fixture(name, precision, tmp_path):
+    from oracle import dockauv_oracle as orc
+    g = H.load(name)
+    T = int(g["meta_T"])
+    n_u = int(g["meta_n_u"])
+    N, sel = 130, [3, 64, 129]                      # three copies of the trajectory among idle envs, two groups
+    env, max_caps, max_sph = H.make_batched(g, N, precision, auto_reset=False)
+    try:
+        store = env.enable_episode_storage(sel, str(tmp_path), title="t", capacity=max(int(g["meta_max_timesteps"]) + 2, 64))
+        _, _, _, _, w = H.prestep_inputs(g)
+        ep_start = g["ep_start"].tolist()
+        env.reset()
+        e = -1
+        for t in range(T):
+            if t in ep_start:
+                e += 1
+                ep = H.episode_arrays(g, [e] * len(sel), max_caps, max_sph)
+                env.reset_envs(sel, ep)
+            a = np.zeros((N, env.n_u))
+            a[sel, :n_u] = g["action"][t]
+            noise = np.zeros(N)
+            noise[sel] = w[t]
+            env.step(a, noise=noise)
+        store.flush()
+        n_ep_done = int(g["done"].sum())
+        assert len(store.files) == n_ep_done * len(sel)
+        tol = dict(f64=dict(state=1e-9, obs=3e-7, rew=1e-8, sd=1e-7), f32=dict(state=2e-4, obs=1e-4, rew=2e-3, sd=5e-3))[precision]
+        ends = np.flatnonzero(g["done"])
+        # oracle run for the full state_dot
+        o, env_name = _oracle_for(g)
+        sd_ref = np.zeros((T, 12))
+        e = -1
+        for t in range(T):
+            if t in ep_start:
+                e += 1
+                from tests.test_oracle_golden import episode_from_golden
+                o.reset(episode=episode_from_golden(g, e))
+            o.step(g["action"][t], noise=float(w[t]))
+            sd_ref[t] = o.state_dot
+        np.testing.assert_allclose(sd_ref[:, 3:6], g["euler_dot"], atol=1e-9)    # the oracle's rows against the reference
+        for env_id in sel:
+            files = [f for f in store.files if f"__ENV_{env_id}__" in f]
+            assert len(files) == n_ep_done
+            for k, f in enumerate(files):
+                st = pickle.load(open(f, "rb"))
+                a0 = ep_start[k]
+                a1 = int(ends[k])
+                rows = slice(a0, a1 + 1)
+                assert st["episode"] == k + 1 and st["env_index"] == env_id
+                assert st["vehicle"]["states"].shape == (a1 - a0 + 2, 12)
+                np.testing.assert_allclose(st["vehicle"]["states"][0, 0:3], g["ep_position"][k], atol=tol["state"])
+                np.testing.assert_allclose(st["vehicle"]["states"][0, 3:6], g["ep_attitude"][k], atol=tol["state"])
+                lin = [0, 1, 2, 6, 7, 8, 9, 10, 11]
+                np.testing.assert_allclose(st["vehicle"]["states"][1:][:, lin], g["state"][rows][:, lin], atol=tol["state"])
+                assert H.angle_diff(st["vehicle"]["states"][1:, 3:6], g["state"][rows, 3:6]).max() <= tol["state"]
+                np.testing.assert_allclose(st["vehicle"]["u"][1:], g["u"][rows], atol=tol["state"])
+                assert not st["vehicle"]["u"][0].any() and not st["vehicle"]["states_dot"][0].any()
+                np.testing.assert_allclose(st["vehicle"]["states_dot"][1:], sd_ref[rows], rtol=tol["sd"], atol=tol["sd"])
+                np.testing.assert_allclose(st["nu_c"][1:, 0:3], g["nu_c"][rows, 0:3], atol=tol["state"])
+                wrap = np.abs(np.abs(g["nav"][rows, 2]) - np.pi) < 1e-3
+                ray_ok = (np.abs(st["observation"][1:, 16:] - g["obs"][rows, 16:]) < 1e-3).all(axis=1)   # f32: grazing-ray flips
+                ok = ~wrap & ray_ok
+                assert ok.mean() > 0.95
+                np.testing.assert_allclose(st["observation"][1:][ok], g["obs"][rows][ok], atol=tol["obs"])
+                np.testing.assert_allclose(st["rewards"][1:][ok], g["reward_arr"][rows][ok], rtol=tol["rew"], atol=tol["rew"])
+                assert st["conditions_last_step"] != 0 and st["meta_data_reward"][0] == "Nav_delta_d"
+    finally:
+        env.close()
+
+
+def _oracle_for(g):
+    from tests.test_oracle_golden import env_from_meta
+    return env_from_meta(g)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_state_dot_output_matches_oracle(precision):
+    """dockauv_step_io.state_dot (AUVSim._state_dot, auvsim.py:108) on random states against the oracle's auv_step."""
+    from gym_dockauv_amd import _capi
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    from oracle import dockauv_oracle as orc
+    for veh, h in (("BlueROV2", 0.1), ("LAUV", 0.02)):
+        import copy
+        from gym_dockauv_amd.config.env_config import BASE_CONFIG
+        cfg = copy.deepcopy(BASE_CONFIG)
+        cfg["vehicle"], cfg["t_step_size"] = veh, h
+        N = 96
+        rs = np.random.RandomState(3)
+        env = BatchedDocking3d(cfg, num_envs=N, scenario="SimpleCurrentDocking3d", precision=precision, reset_mode="none", rng="batched")
+        try:
+            env._gen = np.random.default_rng(2)
+            env.reset()
+            state = env.state
+            state[:, 6:12] = rs.uniform(-0.3, 0.3, (N, 6))
+            env.set_field(_capi.F_STATE, state)
+            cur = env.get_field(_capi.F_CURRENT)
+            a = rs.uniform(-1, 1, (N, env.n_u))
+            env.step(a, extras=True)
+            sd = np.asarray(env.state_dot, dtype=np.float64)
+            model = orc.VehicleModel(orc.VEHICLE_KINDS[veh])
+            for i in range(N):
+                c = orc.CurrentState(mu=0.005, V_min=cur[i, 1], V_max=cur[i, 2], V_c=cur[i, 0], alpha=cur[i, 3], beta=cur[i, 4], sigma=0.0)
+                c.sim(h, 0.0)
+                nu_c = c.body(state[i, 3:6])
+                _, _, sd_ref = orc.auv_step(model, state[i], np.zeros(model.n_u), a[i, :model.n_u], nu_c, h)
+                np.testing.assert_allclose(sd[i], sd_ref, rtol=1e-7 if precision == "f64" else 2e-3, atol=1e-8 if precision == "f64" else 2e-4)
+        finally:
+            env.close()

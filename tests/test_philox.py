@@ -21,3 +21,13 @@ def test_episode_uniforms_shape_and_range():
     assert abs(U.mean() - 0.5) < 0.01
     U2 = P.episode_uniforms(12345, np.arange(1000), np.full(1000, 4))
     assert not np.allclose(U, U2)
+
+
+def test_philox_normal_is_standard_normal():
+    z = P.philox_normal(12345, np.arange(200000), np.full(200000, 3), np.arange(200000) % 1000)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1.0) < 0.01 and np.isfinite(z).all()
+    assert abs(((z > 1.0).mean()) - 0.158655) < 0.004
+    # a different step or env gives a different draw, the same counter the same one
+    a = P.philox_normal(7, np.array([5]), np.array([2]), np.array([9]))
+    assert a == P.philox_normal(7, np.array([5]), np.array([2]), np.array([9]))
+    assert a != P.philox_normal(7, np.array([5]), np.array([2]), np.array([10]))

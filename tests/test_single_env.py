@@ -95,7 +95,7 @@ def test_array_list_and_storage_schema(tmp_path):
     a = ArrayList(np.arange(3.0))
     for i in range(450):
         a.add_row(np.full(3, i))
-    assert a.get_nparray().shape == (451, 3) and a[450, 0] == 449 and a.capacity == 1600
+    assert a.get_nparray().shape == (451, 3) and a[450, 0] == 449 and a.size == 451 and a[0, 2] == 2.0
     auv = types.SimpleNamespace(state=np.zeros(12), u=np.zeros(6), u_bound=np.array([[-1.0, 1.0]] * 6), safety_radius=1, name="x")
     env = types.SimpleNamespace(auv=auv, radar=types.SimpleNamespace(end_pos_n=np.zeros((63, 3))), cum_reward_arr=np.zeros(13),
                                 last_reward_arr=np.zeros(13), observation=np.zeros(36, np.float32), meta_data_reward=["r"] * 13,
