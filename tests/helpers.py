@@ -180,3 +180,27 @@ def check_teacher_forced(env, obs, rew, done, gold, precision, name):
     assert np.array_equal(env.t_steps, gold["t_steps"])
     return dict(obs=float(np.abs(obs[~wrap] - gold["obs"][~wrap]).max()), rew=float(np.abs(rew[~wrap] - gold["reward"][~wrap]).max()),
                 excluded=float(wrap.mean()))
+
+
+# ------------------------------------------------------------------------------------------------ product (lean) kernels
+class DeviceStepper:
+    """Steps a BatchedDocking3d through dockauv_step on DEVICE pointers with the mandatory outputs only (packed rows
+    obs | reward | done): the call that is served by the product instantiations of the step kernel (the host-pointer
+    path with its optional outputs goes to the full-output instantiations)."""
+
+    def __init__(self, env):
+        import torch
+        self.torch = torch
+        self.env = env
+        self.dev = torch.device("cuda", env.device)
+        self.out = torch.zeros((env.num_envs, env.n_observations + 2), device=self.dev, dtype=torch.float32)
+
+    def step(self, actions):
+        torch = self.torch
+        dt = torch.float64 if self.env.precision == "f64" else torch.float32
+        a = torch.as_tensor(np.ascontiguousarray(actions), dtype=dt, device=self.dev).contiguous()
+        self.env.step_device(a.data_ptr(), self.out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, packed=True)
+        torch.cuda.synchronize()
+        o = self.out.cpu().numpy()
+        n = self.env.n_observations
+        return o[:, :n].copy(), o[:, n].copy(), o[:, n + 1] > 0.5

@@ -57,6 +57,22 @@ def run_tiled(names, n_envs, precision="f32", threads=0):
         H.load_teacher_forced(env, inp)
         obs, rew, done, _ = env.step(inp["actions"][:, :env.n_u], noise=inp["noise"], extras=True)
         res = H.check_teacher_forced(env, obs, rew, done, gold, precision, "+".join(names) + f" x{n_envs}")
+        # ... and the PRODUCT instantiation of the kernel (device pointers, mandatory outputs only: what bench.py and
+        # the torch envs launch) from the same inputs: every env against its golden row as well
+        ray_ok = ~(np.abs(env.intersec_dist - gold["ray_dist"]) > H.TOL[precision]["ray"]).any(axis=1)
+        H.load_teacher_forced(env, inp)
+        o2, r2, d2 = H.DeviceStepper(env).step(inp["actions"][:, :env.n_u])
+        tol = H.TOL[precision]
+        ok = ray_ok & ~(np.abs(np.abs(gold["nav"][:, 2]) - np.pi) < 1e-3)
+        np.testing.assert_allclose(o2[ok], gold["obs"][ok], rtol=0, atol=tol["obs"])
+        # (the packed row carries the reward as float32)
+        np.testing.assert_allclose(r2[ok], gold["reward"][ok], rtol=max(tol["rew_rel"], 2e-7), atol=max(tol["rew_abs"], 2e-7))
+        assert (d2 == gold["done"]).mean() > 0.99
+        new_state = env.state
+        lin = [0, 1, 2, 6, 7, 8, 9, 10, 11]
+        np.testing.assert_allclose(new_state[:, lin], gold["state"][:, lin], rtol=0, atol=tol["state"])
+        assert H.angle_diff(new_state[:, 3:6], gold["state"][:, 3:6]).max() <= tol["state"]
+        assert np.array_equal(env.t_steps, gold["t_steps"])
         # the batch is made of copies: copies of the same golden step must also agree with each other bit for bit
         T0 = int(gs[0]["meta_T"]) * K
         if n_envs >= 2 * T0:

@@ -9,6 +9,8 @@ import copy
 import numpy as np
 import pytest
 
+from tests import helpers as H
+
 pytestmark = pytest.mark.gpu
 
 SCN = ["SimpleDocking3d", "SimpleCurrentDocking3d", "CapsuleDocking3d", "CapsuleCurrentDocking3d",
@@ -185,43 +187,71 @@ def test_torch_env_matches_host_path():
         henv.close()
 
 
+def _layout_cases():
+    import copy
+    from gym_dockauv_amd.config.env_config import BASE_CONFIG
+    lauv = copy.deepcopy(BASE_CONFIG)
+    lauv["vehicle"], lauv["t_step_size"] = "LAUV", 0.02
+    h002 = copy.deepcopy(BASE_CONFIG)
+    h002["t_step_size"] = 0.02
+    fan16 = copy.deepcopy(BASE_CONFIG)
+    fan16["radar"].update(alpha=30 * np.pi / 180, beta=30 * np.pi / 180, ray_per_deg=10 * np.pi / 180)
+    mixed = ["BlueROV2" if i % 2 == 0 else "LAUV" for i in range(333)]
+    base = copy.deepcopy(BASE_CONFIG)
+    for c in (base, lauv, h002, fan16):
+        c["max_timesteps"] = 17          # every env runs into t_max twice in 40 steps: in-kernel resets in every case
+    return [("SimpleCurrentDocking3d", base, None, (64, 128, 256)),
+            ("ObstaclesCurrentDocking3d", base, None, (64, 256, 512)),
+            ("ObstaclesDocking3d", lauv, None, (64, 256, 512)),
+            ("SphereDocking3d", fan16, None, (64, 256, 512)),
+            ("ObstaclesCurrentDocking3d", h002, mixed, (64, 256, 512))]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("scenario,layouts", [("SimpleCurrentDocking3d", (64, 128, 256)), ("ObstaclesCurrentDocking3d", (64, 256, 512))])
-def test_wave_layouts_agree(scenario, layouts):
-    """One wave per group (everything in wave 0) vs several (bookkeeper wave: reward / reset / write-back, prefetch
-    waves, ray stage spread over all): the same arithmetic on the same inputs, so the same trajectories incl. in-kernel
-    resets.  (Not bit for bit: the variants are separate instantiations and the compiler contracts a few
-    multiply-adds differently, 1-2 ulp per step; the dynamics are damped, so the difference stays at that level.)"""
+@pytest.mark.parametrize("case", range(5))
+def test_wave_layouts_and_product_kernels_agree(case):
+    """The product instantiations of the step kernel (device pointers, mandatory outputs only) in every group layout
+    -- one wave per group (everything in wave 0) up to eight (bookkeeper / resetter / observation waves, prefetch waves,
+    ray passes spread over all, two integrating waves for mixed batches) -- against the full-output instantiation that
+    the host-pointer path runs (and that the golden-vector tests check): the same arithmetic on the same inputs, so
+    the same trajectories incl. in-kernel resets.  (Not bit for bit: separate instantiations, the compiler contracts a
+    few multiply-adds differently, 1-2 ulp per step; the dynamics are damped, so the difference stays at that level.)"""
+    from gym_dockauv_amd import _capi
     from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    scenario, cfg, vehicles, layouts = _layout_cases()[case]
     N, K = 333, 40
-    outs = []
+
+    def make(th):
+        env = BatchedDocking3d(cfg, num_envs=N, scenario=scenario, precision="f32", reset_mode="device", device_seed=5,
+                               rng="batched", threads_per_group=th, vehicles=vehicles)
+        env._gen = np.random.default_rng(4)
+        env.reset()
+        return env
+
+    rs = np.random.RandomState(9)
+    acts = rs.uniform(-1, 1, (K, N, 6))
+    ref = make(0)
+    try:
+        acts = acts[:, :, :ref.n_u]
+        tr_ref = [ref.step(acts[k]) for k in range(K)]
+        state_ref, goal_ref = ref.state.copy(), ref.get_field(_capi.F_GOAL).copy()
+    finally:
+        ref.close()
+    assert sum(int(t[2].sum()) for t in tr_ref) > 0, "the run must cover in-kernel resets"
     for th in layouts:
-        env = BatchedDocking3d(num_envs=N, scenario=scenario, precision="f32", reset_mode="device", device_seed=5,
-                               rng="batched", threads_per_group=th)
+        env = make(th)
         try:
-            env._gen = np.random.default_rng(4)
-            env.reset()
-            rs = np.random.RandomState(9)
-            tr = []
+            stepper = H.DeviceStepper(env)
             for k in range(K):
-                o, r, d, infos = env.step(rs.uniform(-1, 1, (N, env.n_u)), extras=True)
-                tr.append((o, r, d, env.last_reward_arr.copy(), env.conditions.copy(),
-                           np.stack([infos[i]["terminal_observation"] for i in np.flatnonzero(d)]) if d.any() else None))
-            outs.append((tr, env.state.copy(), env.get_field(7 if False else 2).copy()))
+                o, r, d = stepper.step(acts[k])
+                o1, r1, d1, _ = tr_ref[k]
+                assert np.array_equal(d, d1), f"threads {th} step {k}"
+                np.testing.assert_allclose(o, o1, rtol=0, atol=2e-6, err_msg=f"threads {th} step {k}")
+                np.testing.assert_allclose(r, r1, rtol=2e-6, atol=2e-6)
+            np.testing.assert_allclose(env.state, state_ref, rtol=0, atol=5e-6)
+            np.testing.assert_allclose(env.get_field(_capi.F_GOAL), goal_ref, rtol=0, atol=5e-6)
         finally:
             env.close()
-    assert sum(int(t[2].sum()) for t in outs[0][0]) > 0, "the run must cover in-kernel resets"
-    for other in outs[1:]:
-        for (o1, r1, d1, t1, c1, z1), (o2, r2, d2, t2, c2, z2) in zip(outs[0][0], other[0]):
-            assert np.array_equal(d1, d2) and np.array_equal(c1, c2)
-            np.testing.assert_allclose(o1, o2, rtol=0, atol=2e-6)
-            np.testing.assert_allclose(r1, r2, rtol=2e-6, atol=2e-6)
-            np.testing.assert_allclose(t1, t2, rtol=2e-6, atol=2e-6)
-            assert (z1 is None) == (z2 is None)
-            if z1 is not None:
-                np.testing.assert_allclose(z1, z2, rtol=0, atol=2e-6)
-        np.testing.assert_allclose(outs[0][1], other[1], rtol=0, atol=5e-6)
-        np.testing.assert_allclose(outs[0][2], other[2], rtol=0, atol=5e-6)
 
 
 @pytest.mark.parametrize("precision", ["f64", "f32"])
