@@ -677,6 +677,17 @@ int dockauv_step_gather_sequence(dockauv_handle h, const dockauv_step_io* ios, i
         // the gather of step t rides in the grid of step kernel t + 1 (dockauv_ride.h); the last one is flushed by a
         // gather kernel of its own, so that on return everything queued here is covered by the stream
         if (h->f64 || !h->sym) return fail(h, DOCKAUV_E_INVALID, "lag 1 needs the float kernels of the structural fast path");
+        {
+            // ... and a step the product instantiations serve (dockauv_step.hip.inc: launch_vk)
+            int pl = 0;
+            while ((1 << pl) < h->n_rays) ++pl;
+            const bool odd_fan = h->has_rays && !(pl == 6 || pl == 4);
+            if (h->cfg.reset_mode == DOCKAUV_RESET_POOL || h->cfg.reward_set == 2 || odd_fan || h->trace_dev || h->cfg.device_noise)
+                return fail(h, DOCKAUV_E_INVALID, "lag 1 needs the product kernels (no pool reset, reward set 1, fans of 9-16 or 33-64 rays, no logging)");
+            for (int i = 0; i < n; ++i)
+                if (ios[i].noise || ios[i].reward_terms || ios[i].conditions || ios[i].nav || ios[i].ray_dist || ios[i].terminal_obs || ios[i].state_dot)
+                    return fail(h, DOCKAUV_E_INVALID, "lag 1 needs the product kernels: step %d asks for optional inputs / outputs", i);
+        }
         if (n_plans < 4) return fail(h, DOCKAUV_E_INVALID, "lag 1 needs at least 4 plans (gather buffers)");
         for (int i = 1; i < n; ++i)
             if (ios[i].obs == ios[i - 1].obs)
