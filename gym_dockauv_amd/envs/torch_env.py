@@ -83,10 +83,11 @@ class ShardedTorchDocking3d:
     the TOTAL over the ranks of the ``torch.distributed`` group, rank r owns the contiguous range
     ``shard_range(num_envs, world, r)``; ``step`` takes the learner's action batch (global ``[num_envs, n_u]`` -- the
     rank's rows are sliced out in place -- or just the local rows), steps the rank's shard and returns GLOBAL
-    ``(obs, reward, done)``: every rank's packed rows, gathered by the peer-to-peer transport (``transport="p2p"``,
-    gym_dockauv_amd/parallel.py: P2PGather, closed loop: all rows of step t are there when the returned views are read
-    on the current stream) or by one RCCL all-gather (``"rccl"``).  The views stay valid for two further steps (p2p)
-    / until the next step (rccl).
+    ``(obs, reward, done)``: every rank's packed rows, gathered by one RCCL all-gather (``transport="rccl"``, the
+    default) or by the peer-to-peer transport (``"p2p"``, gym_dockauv_amd/parallel.py: P2PGather, closed loop: all rows
+    of step t are there when the returned views are read on the current stream; accepted only after a bit-exact
+    start-up check against RCCL, watched for late peers).  The views stay valid until the next step (rccl) / for two
+    further steps (p2p).
 
         dist.init_process_group("nccl", ...)
         env = ShardedTorchDocking3d(TRAIN_CONFIG, num_envs=8 * 32768, scenario="ObstaclesDocking3d", device=local_rank)
@@ -95,12 +96,20 @@ class ShardedTorchDocking3d:
     """
 
     def __init__(self, env_config: dict = BASE_CONFIG, num_envs: int = 4096, scenario: str = "SimpleDocking3d",
-                 device: int = 0, transport: str = "p2p", group=None, device_seed: int = 0, host_seed: Optional[int] = None,
-                 vehicles=None, **kw):
+                 device: int = 0, transport: str = "rccl", group=None, device_seed: int = 0, host_seed: Optional[int] = None,
+                 vehicles=None, verify_steps: int = 4, check_every: int = 64, p2p_max_spins: int = 8_000_000, **kw):
+        """transport: "rccl" (default: one all_gather_into_tensor per step, what BASELINE.json names) or "p2p" (the
+        peer-to-peer push of gym_dockauv_amd/parallel.py).  p2p is only kept if, on EVERY rank, `verify_steps` gathers of
+        test rows equal an RCCL all-gather of the same rows bit for bit; otherwise the env falls back to RCCL
+        (``self.transport`` says which one runs, ``self.transport_note`` why).  With p2p the time-out word of the
+        transport is read every `check_every` steps and in close(): a peer whose step stamp did not arrive within the
+        spin bound makes step() raise DockAUVError on every rank that waited for it (the rows it would have returned
+        are stale) -- the job is then to be restarted as fresh processes."""
         import numpy as np
         import torch
         import torch.distributed as dist
         from ..parallel import P2PShardedStepper, ShardedStepper, shard_range
+        from .._capi import DockAUVError
         self.torch = torch
         if not torch.cuda.is_available():
             raise RuntimeError("ShardedTorchDocking3d needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -123,19 +132,65 @@ class ShardedTorchDocking3d:
             self.batch._gen = np.random.default_rng(host_seed + self.rank)
         self.n_obs, self.n_u = self.batch.n_observations, self.batch.n_u
         self.observation_space, self.action_space = self.batch.observation_space, self.batch.action_space
-        self.transport = transport
+        self.transport, self.transport_note = transport, None
+        self.check_every = max(1, int(check_every))
+        self._steps = 0
+        self._DockAUVError = DockAUVError
 
         def step_fn(actions_local, out_local):
             self.batch.step_device(actions_local.data_ptr(), out_local.data_ptr(),
                                    stream=torch.cuda.current_stream().cuda_stream, packed=True)
 
+        def rccl_stepper():
+            return ShardedStepper(self.n_local, self.n_obs + 2, step_fn, self.device, world=self.world,
+                                  rank=self.rank, group=group, overlap=False)
+
         if transport == "p2p":
-            self.stepper = P2PShardedStepper(self.n_local, self.n_obs + 2, step_fn, self.device, world=self.world,
-                                             rank=self.rank, group=group, overlap=False)
+            p2p, note = None, None
+            try:
+                p2p = P2PShardedStepper(self.n_local, self.n_obs + 2, step_fn, self.device, world=self.world,
+                                        rank=self.rank, group=group, overlap=False, max_spins=p2p_max_spins)
+            except (DockAUVError, ValueError) as e:      # (P2PGather agrees across ranks: all raise or none)
+                note = f"p2p set-up failed ({e}): RCCL used"
+            if p2p is not None and self.world > 1 and verify_steps > 0:
+                # the transport itself, without stepping the envs: test rows through the gather vs. an RCCL all-gather
+                ok = 1
+                ref = torch.empty((self.world * self.n_local, self.n_obs + 2), device=self.device, dtype=torch.float32)
+                stream = torch.cuda.current_stream().cuda_stream
+                gen = torch.Generator(device=self.device)
+                gen.manual_seed(1000 + self.rank)
+                for i in range(int(verify_steps)):
+                    rows = p2p.rows2[p2p.gather.t & 1]
+                    rows.copy_(torch.rand(rows.shape, device=self.device, generator=gen))
+                    buf = p2p.gather.gather(rows.data_ptr(), stream)
+                    dist.all_gather_into_tensor(ref, rows, group=group)
+                    ok &= int(torch.equal(buf.view(torch.int32), ref.view(torch.int32)))
+                ok &= int(p2p.gather.timed_out() == 0)
+                flag = torch.tensor([ok], device=self.device, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                if int(flag.item()) != 1:
+                    note = "p2p rows differed from the RCCL all-gather (or a stamp timed out) in the start-up check: RCCL used"
+                    p2p.close()
+                    p2p = None
+            if p2p is None:
+                self.transport, self.transport_note = "rccl", note
+                self.stepper = rccl_stepper()
+            else:
+                self.stepper = p2p
         else:
-            self.stepper = ShardedStepper(self.n_local, self.n_obs + 2, step_fn, self.device, world=self.world,
-                                          rank=self.rank, group=group, overlap=False)
+            self.stepper = rccl_stepper()
         self._zeros = None
+
+    def _check_transport(self) -> None:
+        """p2p: a peer's stamp that did not arrive within the spin bound is sticky in the status word (every later wait
+        returns at once and the gather buffers would hand out rows of an earlier step)."""
+        if self.transport != "p2p":
+            return
+        late = self.stepper.gather.timed_out()
+        if late:
+            raise self._DockAUVError(f"rank {self.rank}: the step stamps of rank(s) {[r for r in range(self.world) if late >> r & 1]} "
+                                     f"did not arrive within the spin bound after {self._steps} steps: the gathered rows are "
+                                     "stale; restart the job")
 
     def reset(self, seed: Optional[int] = None):
         """All envs of this rank's shard: new episodes; returns the reference's reset observation for ALL envs (zeros,
@@ -156,9 +211,19 @@ class ShardedTorchDocking3d:
         elif tuple(actions.shape) != (self.n_local, self.n_u):
             raise ValueError(f"actions must be [{self.num_envs}, {self.n_u}] (global) or [{self.n_local}, {self.n_u}] (local)")
         buf = self.stepper.step(actions)
+        self._steps += 1
+        if self._steps % self.check_every == 0:
+            self._check_transport()
         return buf[:, : self.n_obs], buf[:, self.n_obs], buf[:, self.n_obs + 1] > 0.5
 
     def close(self) -> None:
+        err = None
+        try:
+            self._check_transport()
+        except Exception as e:          # still release everything; re-raise afterwards
+            err = e
         if hasattr(self.stepper, "close"):
             self.stepper.close()
         self.batch.close()
+        if err is not None:
+            raise err

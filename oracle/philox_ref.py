@@ -1,7 +1,7 @@
 """
 oracle/philox_ref.py -- NumPy restatement of the Philox4x32-10 counter RNG (Salmon, Moraes, Dror, Shaw: "Parallel
 random numbers: as easy as 1, 2, 3", SC'11; constants of the Random123 reference implementation) and of the
-counter/key convention of the in-kernel episode generator (gym_dockauv_amd/csrc/dockauv_kernels.hip).
+counter/key convention of the in-kernel episode generator (gym_dockauv_amd/csrc/dockauv_step.hip.inc).
 
 TEST INFRASTRUCTURE ONLY.  Pinned by the Random123 known-answer vectors in tests/test_philox.py.
 """

@@ -19,6 +19,35 @@ def main() -> int:
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     stream = torch.cuda.current_stream().cuda_stream
+    if os.environ.get("P2P_WORKER_MODE") == "stall":
+        # a peer that stops stepping: the surviving rank's ShardedTorchDocking3d.step must RAISE (not hand out stale rows)
+        from gym_dockauv_amd._capi import DockAUVError
+        from gym_dockauv_amd.envs.torch_env import ShardedTorchDocking3d
+        try:
+            sh = ShardedTorchDocking3d(BASE_CONFIG, num_envs=world * n_local, scenario="SimpleCurrentDocking3d", device=0,
+                                       transport="p2p", device_seed=900, host_seed=70, check_every=8, p2p_max_spins=200_000)
+            assert sh.transport == "p2p", sh.transport_note
+            sh.reset()
+            a = torch.zeros((world * n_local, sh.n_u), device=dev)
+            raised = False
+            n_steps = steps if rank == 0 else 5          # rank 1 (and above) stop after five steps
+            try:
+                for t in range(n_steps):
+                    sh.step(a)
+            except DockAUVError as e:
+                raised = True
+                print(f"rank {rank}: step raised as it must: {e}", flush=True)
+            if rank == 0:
+                assert raised, "rank 0 kept stepping on stale rows"
+            else:
+                import time
+                time.sleep(3.0)                          # long enough for rank 0 to run out of spins
+            # (no collective from here on: the job is broken by design; each rank releases its own resources)
+            sh.batch.close()
+            print(f"rank {rank}: stall rehearsal done, 0 bad", flush=True)
+            os._exit(0)
+        finally:
+            pass
     try:
         # every rank also steps private copies of the OTHER ranks' shards (same seeds -> same rows, the kernel is
         # deterministic): the gathered buffer must equal their concatenation bit for bit

@@ -77,6 +77,52 @@ def test_rank_processes_on_one_gpu_gather_bit_exact(world):
         print("".join(l + "\n" for l in out.splitlines() if " us " in l), end="")    # pace lines (pytest -s)
 
 
+def test_sharded_env_raises_when_a_peer_stops():
+    """Two rank processes on the one GPU; rank 1 stops stepping after five steps: rank 0's ShardedTorchDocking3d.step
+    must raise DockAUVError within check_every steps of the time-out instead of handing out rows of an earlier step."""
+    port = 29950 + (os.getpid() % 40)
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", P2P_WORKER_MODE="stall")
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.p2p_worker", str(r), "2", str(port), "640", "400"],
+                              cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=180)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{out[-3000:]}"
+        assert "0 bad" in out
+    assert "step raised as it must" in outs[0]
+
+
+def test_sharded_env_checks_the_transport_status():
+    """One rank: a time-out word set behind the env's back (what a late peer leaves) surfaces as DockAUVError from
+    step() at the next check and from close()."""
+    import torch
+    from gym_dockauv_amd._capi import DockAUVError
+    from gym_dockauv_amd.envs.batched import BASE_CONFIG
+    from gym_dockauv_amd.envs.torch_env import ShardedTorchDocking3d
+    e = ShardedTorchDocking3d(BASE_CONFIG, num_envs=128, transport="p2p", check_every=4)
+    assert e.transport == "p2p"
+    e.reset()
+    a = torch.zeros((128, e.n_u), device=e.device)
+    for _ in range(8):
+        e.step(a)
+    e.stepper.gather._status_view[0] = 0b10
+    with pytest.raises(DockAUVError):
+        for _ in range(4):
+            e.step(a)
+    with pytest.raises(DockAUVError):
+        e.close()
+    e2 = ShardedTorchDocking3d(BASE_CONFIG, num_envs=128)
+    assert e2.transport == "rccl"          # the default (BASELINE.json: RCCL all-gather)
+    e2.close()
+
+
 def test_sequence_argument_checks():
     """dockauv_step_gather_sequence refuses what would race: fewer than 4 plans or one row buffer with riding gathers."""
     import ctypes as C
