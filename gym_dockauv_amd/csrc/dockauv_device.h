@@ -65,6 +65,7 @@ struct EnvP {
 // rounded up to a multiple of 64 so that every row starts 256-B aligned.
 struct Buffers {
     void* state;      // T [12][S]
+    void* pos_lo;     // T [3][S]   low-order words of the position (compensated accumulation: position = state[0:3] + pos_lo)
     void* u;          // T [kMaxU][S]
     void* goal;       // T [4][S]   x y z heading
     void* cur;        // T [6][S]   V_c, dir_x, dir_y, dir_z (NED unit vector), V_min, V_max

@@ -40,7 +40,9 @@ def test_teacher_forced_f32(name):
 def run_free(name, precision, tol_obs, tol_rayobs, tol_rew):
     """Free-running: only actions and episodes are given; the state is carried by the kernel across all steps
     (hundreds of steps, several episodes).  Steps where a ray flips hit/miss at grazing incidence (|dd| > 1 mm;
-    unbounded condition number) are excluded from the obs / reward comparison and their number is bounded."""
+    unbounded condition number) are excluded from the obs / reward comparison and their number is bounded.  obs[2] =
+    delta_psi / pi lives on a circle (ssa wraps it at +-1): it is compared modulo 2, so steps at the wrap are checked
+    like any other (the reward term of delta_psi is even and continuous there)."""
     g = H.load(name)
     T = int(g["meta_T"])
     n_u = int(g["meta_n_u"])
@@ -61,9 +63,11 @@ def run_free(name, precision, tol_obs, tol_rayobs, tol_rew):
             assert bool(done[0]) == bool(g["done"][t]), f"{name}: done differs at step {t}"
             flip = bool((np.abs(env.intersec_dist[0] - g["ray_dist"][t]) > 1e-3).any())
             flips += flip
-            if flip or abs(abs(g["nav"][t, 2]) - np.pi) < 1e-3:
+            if flip:
                 continue
-            worst_obs = max(worst_obs, float(np.abs(obs[0, :16] - g["obs"][t, :16]).max()))
+            d = np.abs(obs[0, :16] - g["obs"][t, :16])
+            d[2] = min(d[2], 2.0 - d[2])
+            worst_obs = max(worst_obs, float(d.max()))
             worst_ray = max(worst_ray, float(np.abs(obs[0, 16:] - g["obs"][t, 16:]).max()))
             worst_rew = max(worst_rew, float(abs(rew[0] - g["reward"][t]) / max(1.0, abs(g["reward"][t]))))
         assert flips <= max(2, T // 100), f"{name}: {flips} steps with a flipped ray"
@@ -76,9 +80,13 @@ def run_free(name, precision, tol_obs, tol_rayobs, tol_rew):
 
 @pytest.mark.parametrize("name", H.TRAJ)
 def test_free_running_f32(name):
-    # step-for-step against the float64 reference over whole multi-episode trajectories
-    # measured drift (tests/drift_report.py): obs[:16] <= 2.4e-5, ray obs <= 5.4e-5, reward <= 8e-6 relative
-    run_free(name, "f32", 5e-5, 1e-4, 5e-5)
+    # step-for-step against the float64 reference over whole multi-episode trajectories (up to 400 steps, nothing pulls
+    # the float32 state back to the reference's).  Measured (profiles/r2/parity_drift_f32.txt): obs[:16] <= 1.8e-5 --
+    # 15 of 19 trajectories <= 1e-5; the four above it are the goto runs that END at the goal, where obs[0..2] divide by a
+    # distance of ~0.5 m (position is an undamped integrator: velocity rounding of ~3e-7 m/s integrates to ~1e-5 m over
+    # 26 s; the compensated position sum of round 2 removed the sum's own share, 3e-5 -> 1.8e-5) -- ray cells <= 1e-4
+    # (grazing hits), reward <= 5e-6 relative.  Teacher-forced (every step from the reference's state): 1e-5 everywhere.
+    run_free(name, "f32", 2.5e-5, 1.2e-4, 2e-5)
 
 
 @pytest.mark.parametrize("name", [n for n in H.TRAJ if "config1" in n or "Obstacles" in n])
