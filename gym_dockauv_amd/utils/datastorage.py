@@ -206,7 +206,7 @@ class EpisodeDataStorage:
 class BatchEpisodeStorage:
     """EpisodeDataStorage for selected envs of a BatchedDocking3d, fed from the device trace ring.
 
-    Row layout of a pickle (reference: utils/datastorage.py:254-271, 273-291): index 0 = the values at reset (state the
+    Row layout of a pickle (reference: utils/datastorage.py:262-287, 289-310): index 0 = the values at reset (state the
     episode started from, zeros for state_dot / u / rewards / observation -- Q8: reset returns zeros), index k = after
     step k.  ``nu_c`` rows are 6 wide (last three zero) as in the reference; row 0 repeats the first step's value (the
     reset-time current differs from it by one Gauss-Markov update of V_c)."""
