@@ -41,6 +41,7 @@ HBM_PEAK_GBPS = 8000.0                           # MI355X HBM3E spec peak (MI355
 N_SIMD = 1024                                    # 256 CUs x 4 SIMDs
 CLOCK_MHZ = 2400.0                               # max shader clock (MI355X_MICROARCH.md)
 VALU_CYCLES_PER_INST = 4.0                       # issue slots a wave64 VALU instruction is priced at (x4)
+VALU_CYCLES_MEASURED = 2.1                       # plain fp32 VALU instruction on a saturated SIMD, measured (scripts/micro/issue_rate.hip)
 
 
 def workload(config_id: int, envs: int):
@@ -194,8 +195,12 @@ def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha:
         if e.get("sq_insts_valu"):
             cyc = kernel_us * CLOCK_MHZ
             r["valu_frac"] = e["sq_insts_valu"] * VALU_CYCLES_PER_INST / (N_SIMD * cyc)
+            # the same count priced at what a saturated SIMD was MEASURED to need for a plain fp32 instruction
+            # (profiles/r2/issue_rate.txt: 8.4 cycles per instruction and wave at 4 waves per SIMD; packed, DPP and
+            # transcendental instructions cost 2-4 x that): a lower bound of the SIMDs' busy share
+            r["valu_frac_at_measured_issue_rate"] = e["sq_insts_valu"] * VALU_CYCLES_MEASURED / (N_SIMD * cyc)
             r["valu_frac_inputs"] = {"SQ_INSTS_VALU_per_launch": e["sq_insts_valu"], "cycles_per_inst": VALU_CYCLES_PER_INST,
-                                     "simds": N_SIMD, "kernel_cycles_at_2400MHz": cyc}
+                                     "cycles_per_inst_measured": VALU_CYCLES_MEASURED, "simds": N_SIMD, "kernel_cycles_at_2400MHz": cyc}
     return r
 
 

@@ -55,7 +55,7 @@ def med(i):
 print(f"{wl['name']}  N={N}  (s_memtime ticks relative to the group's start; median over {G} groups x {len(runs)} launches)")
 wave0 = [(6, "first kernarg word arrived"), (1, "loads issued"), (2, "loads landed, nu_c done"), (16, "inputs filtered (vehicle_step_)"), (17, "RHS 1"), (18, "RHS 2"),
          (19, "RHS 3"), (20, "RHS 4"), (21, "RHS 5"), (3, "RK step done"), (14, "pose trig / publish"), (15, "obstacle records complete"),
-         (4, "ray stage done (wave 0)"), (5, "nav + obs done"), (7, "resetter entered"), (8, "reset + write-back issued"), (9, "obs tile stored = end")]
+         (4, "tail of wave 0 entered"), (5, "tail of wave 0 done (nav obs, write-back)"), (7, "resetter entered"), (8, "reset + write-back issued"), (9, "obs tile stored = end")]
 prev = 0.0
 print("  wave 0 (integrating wave):")
 for i, nm in wave0:
@@ -80,13 +80,5 @@ worst = np.nanargmax(tt, axis=1)
 sel = rel[np.arange(rel.shape[0]), worst]          # [launch, stamp]
 print("  slowest sampled group of each launch, medians: " + "  ".join(f"{nm.split()[0]}@{np.nanmedian(sel[:, i]):.0f}" for i, nm in
       ((2, "landed"), (3, "rk"), (14, "publish"), (15, "records"), (4, "raydone"), (5, "navobs"), (8, "wb"), (9, "end")) if not np.all(np.isnan(sel[:, i]))))
-if args.shift >= 3:   # all sampled groups sit on one XCD: one clock
-    s0, s9 = st[:, :, 0].astype(np.float64), st[:, :, 9].astype(np.float64)
-    first = s0.min(axis=1, keepdims=True)
-    print(f"  within a launch (sampled groups of one XCD): start spread median {np.median(s0.max(axis=1) - s0.min(axis=1)):.0f}"
-          f"  end spread {np.median(s9.max(axis=1) - s9.min(axis=1)):.0f}  first start -> last end {np.median(s9.max(axis=1) - s0.min(axis=1)):.0f}")
-    order = np.argsort(np.median(s0 - first, axis=0))
-    print("  start offsets of the sampled groups (median over launches, sorted): " + " ".join(f"{v:.0f}" for v in np.sort(np.median(s0 - first, axis=0))))
-    print("  end offsets (same order): " + " ".join(f"{v:.0f}" for v in np.median(s9 - first, axis=0)[order]))
 print(f"  total {np.nanmedian(total):.0f} ticks")
 env.close()
