@@ -320,9 +320,11 @@ def main():
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)   # child of cpu_baseline_all_cores
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--no-overlap", action="store_true", help="do not overlap the all-gather with the next kernel")
-    ap.add_argument("--gather", choices=["auto", "rccl", "p2p"], default="auto",
-                    help="N > 1: transport of the per-step gather.  auto = peer-to-peer push (dockauv_p2p_*) if it maps "
-                         "and reproduces the RCCL all-gather bit for bit during warm-up, else RCCL")
+    ap.add_argument("--gather", choices=["auto", "rccl", "p2p"], default="rccl",
+                    help="N > 1: transport of the per-step gather.  rccl (default) = one all_gather_into_tensor per step, "
+                         "as BASELINE's north_star names it; auto = peer-to-peer push (dockauv_p2p_*) if it maps and "
+                         "reproduces the RCCL all-gather bit for bit during warm-up, else RCCL (the links bound the step "
+                         "either way, DESIGN.md section 7; the push has only run with ranks sharing one GPU)")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--sweep", type=int, nargs="*", default=[262144, 1048576])
     args = ap.parse_args()
@@ -496,9 +498,31 @@ def main():
         dist.barrier()
         rccl_ms = reduce_max(time.perf_counter() - t0) / k2 * 1e3
 
+    out_l = stepper.rows if transport == "p2p" else stepper.local_slice(stepper.bufs[0])
+
+    # N > 1: the same shard stepped WITHOUT the gather on every rank at the same time (plain step sequences, as the
+    # single-GPU line is measured): the per-GPU rate this workload reaches alone.  The weak-scaling efficiency of the
+    # line is value / (n_gpus * this) -- the default single-GPU line is a different workload (config 3, the headline).
+    alone = None
+    if use_dist:
+        alone_cache = {}
+
+        def run_alone(n, i0=0):
+            key = (n, i0 % RING)
+            if key not in alone_cache:
+                alone_cache[key] = env.make_step_sequence([actions[i % RING].data_ptr() for i in range(i0, i0 + n)],
+                                                          [out_l.data_ptr()] * n, packed=True)
+            env.run_step_sequence(alone_cache[key], stream=stream)
+
+        t_alone = timed_regions(run_alone, args.steps, min(args.warmup, 50), 0, args.min_seconds / 2, args.max_reps,
+                                torch.cuda.synchronize, barrier, reduce_max)
+        d_alone = statistics.median(t_alone)
+        alone = {"per_gpu_value": N * args.steps / d_alone, "unit": "env-steps/s", "ms_per_step": d_alone / args.steps * 1e3,
+                 "reps": len(t_alone), "what": "the same shard on every rank at once, no gather (max over ranks)",
+                 "weak_scaling_efficiency_of_this_line": (world * N * args.steps / dt) / (world * N * args.steps / d_alone)}
+
     # roofline of the dominant (only) kernel: per-dispatch start/stop events on the launch stream, cycling through
     # the same action ring as the timed region
-    out_l = stepper.rows if transport == "p2p" else stepper.local_slice(stepper.bufs[0])
     n_timed = min(max(args.steps, 256), 1024)
     kernel_us = 0.0
     for i in range(n_timed):
@@ -590,6 +614,8 @@ def main():
         }
         if closed:
             out["closed_loop"] = closed
+        if alone:
+            out["same_workload_without_gather"] = alone
         if sweep:
             out["sweep"] = sweep
         if world == 1 and not use_dist and not args.no_configs and not args.envs:
