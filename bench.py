@@ -75,12 +75,16 @@ def workload(config_id: int, envs: int):
 
 
 def kernel_source_sha() -> str:
-    """Identifies the kernel version a profile under profiles/ belongs to."""
+    """Identifies the kernel version a profile under profiles/ belongs to: a hash of the device sources without their
+    comments and blank lines (a comment edit does not make the committed counters stale)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gym_dockauv_amd", "csrc")
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".inc", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
+            for line in open(os.path.join(d, f), encoding="utf-8", errors="replace"):
+                code = line.split("//", 1)[0].rstrip()
+                if code:
+                    h.update(code.encode() + b"\n")
     return h.hexdigest()[:12]
 
 
