@@ -5,8 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
 from gym_dockauv_amd.envs.batched import BatchedDocking3d
-for n in (4096, 65536):
-    wl = bench.workload(2, n)
+for cfg_id, n in ((2, 4096), (2, 65536), (3, 65536)):
+    wl = bench.workload(cfg_id, n)
     env = BatchedDocking3d(wl["cfg"], num_envs=n, scenario=wl["scenario"], precision="f32", reset_mode="device", rng="batched")
     env.reset()
     a = np.random.default_rng(0).uniform(-1, 1, (16, n, env.n_u)).astype(np.float32)
@@ -25,5 +25,5 @@ for n in (4096, 65536):
         env._lib.dockauv_step_host(env._handle, C.byref(io))
     dt_c = time.perf_counter() - t1
     print(f"  dockauv_step_host alone: {dt_c / K * 1e6:.1f} us/step = {n * K / dt_c:.3e} env-steps/s")
-    print(f"host-pointer path, config 2, N={n}: {dt / K * 1e6:.1f} us/step = {n * K / dt:.3e} env-steps/s (PCIe + Python inclusive)")
+    print(f"host-pointer path, config {cfg_id}, N={n}: {dt / K * 1e6:.1f} us/step = {n * K / dt:.3e} env-steps/s (PCIe + Python inclusive)")
     env.close()
