@@ -529,8 +529,8 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
         h->a32.params_dev = h->a64.params_dev = pdev;
     }
     // the dynamic-LDS request must fit the 160 KiB of a gfx950 CU
-    size_t lds = h->f64 ? lds_bytes<double>(64, 512, c.max_capsules, c.max_spheres, h->n_obs, h->has_rays, h->has_rays)
-                        : lds_bytes<float>(64, 512, c.max_capsules, c.max_spheres, h->n_obs, h->has_rays, h->has_rays);
+    size_t lds = h->f64 ? lds_bytes<double>(64, 512, c.max_capsules, c.max_spheres, h->n_obs, h->has_rays)
+                        : lds_bytes<float>(64, 512, c.max_capsules, c.max_spheres, h->n_obs, h->has_rays);
     if (lds > 160 * 1024) {
         fail(nullptr, DOCKAUV_E_INVALID, "configuration needs %zu B of LDS per group (> 160 KiB): fewer rays/obstacles", lds);
         dockauv_destroy(h);

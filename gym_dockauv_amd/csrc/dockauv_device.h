@@ -167,14 +167,14 @@ constexpr int kCapFields = 10;   // body-frame unit axis d(3), oa_perp(3), oa_pa
 constexpr int kSphFields = 4;    // body-frame origin - centre (3), r^2
 constexpr int kPoseFields = 16;  // n_cap, n_sph, position (3), body -> NED rotation (9), may-be-hit bit masks (capsules, spheres)
 constexpr int kSpecFields = 19;  // pre-drawn next episode of an env: pose (6), goal (4), current rows (8), pillar-ring draw
-constexpr int kNavFields = 5;    // integrating wave -> tail roles (SHARE_NAV): distance, delta_theta, delta_psi, condition bits, ready flag
+constexpr int kNavFields = 5;    // integrating wave -> tail roles (SHARE_NAV): distance, delta_theta, delta_psi, condition bits, ready flags;
+                                 // they live in spare rows of the obstacle-avoidance sums (dockauv_step.hip.inc: lds_nav)
 constexpr int kHxFields = 21;    // env phase -> tail waves: state (12), V_c, action penalty, |euler_dot|^2, collision, nu_c (3), sin/cos psi
 
 template <typename T>
-inline size_t lds_bytes(int epg, int nt, int max_cap, int max_sph, int n_obs, bool rays, bool nav = false) {
+inline size_t lds_bytes(int epg, int nt, int max_cap, int max_sph, int n_obs, bool rays) {
     size_t t_elems = rays ? (size_t)epg * (kPoseFields + kCapFields * max_cap + kSphFields * max_sph + 4 * (nt / epg)) : 0;
     if (nt / epg >= 2) t_elems += (size_t)epg * (kHxFields + kSpecFields);
-    if (nav) t_elems += (size_t)epg * kNavFields;
     size_t bytes = t_elems * sizeof(T);
     bytes = (bytes + 15) & ~(size_t)15;
     return bytes + (size_t)epg * (n_obs + 2) * sizeof(float);   // +2: packed reward | done columns

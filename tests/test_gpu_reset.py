@@ -197,6 +197,8 @@ def _layout_cases():
     fan16 = copy.deepcopy(BASE_CONFIG)
     fan16["radar"].update(alpha=30 * np.pi / 180, beta=30 * np.pi / 180, ray_per_deg=10 * np.pi / 180)
     mixed = ["BlueROV2" if i % 2 == 0 else "LAUV" for i in range(333)]
+    # vehicle-sorted: whole 64-env groups of ONE kind inside a mixed batch (an integrating wave of such a group owns no lane)
+    sorted_mixed = ["BlueROV2"] * 192 + ["LAUV"] * 141
     base = copy.deepcopy(BASE_CONFIG)
     for c in (base, lauv, h002, fan16):
         c["max_timesteps"] = 17          # every env runs into t_max twice in 40 steps: in-kernel resets in every case
@@ -204,11 +206,12 @@ def _layout_cases():
             ("ObstaclesCurrentDocking3d", base, None, (64, 256, 512)),
             ("ObstaclesDocking3d", lauv, None, (64, 256, 512)),
             ("SphereDocking3d", fan16, None, (64, 256, 512)),
-            ("ObstaclesCurrentDocking3d", h002, mixed, (64, 256, 512))]
+            ("ObstaclesCurrentDocking3d", h002, mixed, (64, 256, 512)),
+            ("ObstaclesCurrentDocking3d", h002, sorted_mixed, (256,))]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", range(5))
+@pytest.mark.parametrize("case", range(6))
 def test_wave_layouts_and_product_kernels_agree(case):
     """The product instantiations of the step kernel (device pointers, mandatory outputs only) in every group layout
     -- one wave per group (everything in wave 0) up to eight (bookkeeper / resetter / observation waves, prefetch waves,
