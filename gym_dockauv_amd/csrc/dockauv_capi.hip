@@ -64,6 +64,7 @@ struct dockauv_env_s {
         void* actions = nullptr; void* noise = nullptr; float* obs = nullptr; void* reward = nullptr;
         uint8_t* done = nullptr; void* terms = nullptr; uint8_t* cond = nullptr; void* nav = nullptr;
         void* raydist = nullptr; float* termobs = nullptr; void* statedot = nullptr;
+        unsigned int* status = nullptr;   // mirror of the kernels' sticky status word
         bool ready = false;
     } pin;
     std::vector<void*> pinned_allocs;
@@ -96,6 +97,20 @@ int fail(dockauv_handle h, int code, const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                            \
         if (e_ != hipSuccess) return fail(h, DOCKAUV_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// Sticky status word of the handle's kernels, read wherever the host has just synchronised with the stream (4 bytes;
+// no synchronisation of its own beyond the copy).  Non-zero = a step kernel gave up an internal wait: every result since
+// is invalid; the handle stays in that state (the caller destroys it).
+int check_status(dockauv_handle h) {
+    const unsigned int* sw = h->f64 ? h->a64.B.status : h->a32.B.status;
+    if (!sw) return 0;
+    unsigned int v = 0;
+    HIP_TRY(h, hipMemcpy(&v, sw, sizeof v, hipMemcpyDeviceToHost));
+    if (v != 0)
+        return fail(h, DOCKAUV_E_KERNEL, "step kernel status 0x%x: a tail role timed out waiting for its group's integrating wave; "
+                    "results since are invalid, destroy the handle", v);
+    return 0;
+}
 
 int dalloc(dockauv_handle h, void** p, size_t bytes) {
     if (bytes == 0) bytes = 256;
@@ -486,6 +501,11 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
         B.lane_tab = lt_dev;
         B.lane_cell = lc_dev;
     }
+    {
+        void* st_dev = nullptr;   // sticky status word (dockauv_device.h: Buffers::status); dalloc zeroes it
+        ALLOC(st_dev, 256);
+        B.status = static_cast<unsigned int*>(st_dev);
+    }
     // host-pointer staging buffers
     const size_t N = (size_t)c.n_envs;
     ALLOC(h->d_actions, N * h->n_u_max * t);
@@ -620,6 +640,7 @@ int dockauv_get_field(dockauv_handle h, int field, int first, int count, double*
     if (count == 0 || fd.rows == 0) return 0;
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream)); else HIP_TRY(h, hipDeviceSynchronize());
+    if ((rc = check_status(h)) != 0) return rc;
     const size_t es = elem_size(h, fd.kind);
     std::vector<unsigned char> tmp((size_t)fd.rows * count * es);
     const unsigned char* srcp = static_cast<const unsigned char*>(fd.base) + (size_t)first * es;
@@ -811,6 +832,8 @@ int ensure_pinned(dockauv_handle h) {
     if ((rc = pinned_alloc(h, &h->pin.raydist, N * h->n_rays * t))) return rc;
     if ((rc = pinned_alloc(h, (void**)&h->pin.termobs, N * h->n_obs * 4))) return rc;
     if ((rc = pinned_alloc(h, &h->pin.statedot, N * 12 * t))) return rc;
+    if ((rc = pinned_alloc(h, (void**)&h->pin.status, 64))) return rc;
+    *h->pin.status = 0;
     HIP_TRY(h, hipStreamCreate(&h->host_stream));   // blocking stream: ordered after the null-stream copies of set_field / reset_envs
     h->pin.ready = true;
     return 0;
@@ -858,7 +881,11 @@ int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io) {
     if (io->nav) HIP_TRY(h, hipMemcpyAsync(h->pin.nav, h->d_nav, N * 4 * t, hipMemcpyDeviceToHost, s));
     if (io->ray_dist) HIP_TRY(h, hipMemcpyAsync(h->pin.raydist, h->d_raydist, N * h->n_rays * t, hipMemcpyDeviceToHost, s));
     if (io->state_dot) HIP_TRY(h, hipMemcpyAsync(h->pin.statedot, h->d_statedot, N * 12 * t, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(h->pin.status, h->f64 ? h->a64.B.status : h->a32.B.status, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    if (*h->pin.status != 0)
+        return fail(h, DOCKAUV_E_KERNEL, "step kernel status 0x%x: a tail role timed out waiting for its group's integrating wave; "
+                    "results are invalid, destroy the handle", *h->pin.status);
     if (io->terminal_obs) {
         // terminal observations only exist for envs that finished in this step: fetch the rows of those envs only
         // (typically none or a few; the buffer is as large as the observations themselves)
@@ -970,6 +997,7 @@ int dockauv_trace_read(dockauv_handle h, long long first_step, int n_steps, doub
     if (n_steps == 0) return 0;
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream)); else HIP_TRY(h, hipDeviceSynchronize());
+    if (int rc_ = check_status(h)) return rc_;
     const size_t R = (size_t)tr.n_rows;
     std::vector<unsigned char> tmp;
     // one ring array -> host [n_steps][n_rows][w]; kind 0 = T -> double, 1 = float, 2 = uint8
@@ -998,7 +1026,7 @@ int dockauv_synchronize(dockauv_handle h) {
     if (!h) return DOCKAUV_E_INVALID;
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream)); else HIP_TRY(h, hipDeviceSynchronize());
-    return 0;
+    return check_status(h);
 }
 
 int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_stream, int steps, double* avg_us) {
@@ -1023,7 +1051,7 @@ int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_st
     }
     for (auto& e : ev) (void)hipEventDestroy(e);
     *avg_us = total_ms * 1000.0 / steps;
-    return 0;
+    return check_status(h);
 }
 
 #ifdef DOCKAUV_STAMPS
@@ -1031,6 +1059,11 @@ int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_st
 int dockauv_debug_read_stamps(unsigned long long* out) {
     (void)hipDeviceSynchronize();
     return dockauv::read_stamps(out);
+}
+// start / end of every group of the last f32 step on both clocks (scripts/span.py)
+int dockauv_debug_read_span(unsigned long long* out, int groups) {
+    (void)hipDeviceSynchronize();
+    return dockauv::read_span(out, groups);
 }
 #endif
 

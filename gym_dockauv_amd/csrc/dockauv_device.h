@@ -89,6 +89,10 @@ struct Buffers {
     // block-max cell of the ray (sensor.py:131-137)
     const void* lane_tab;
     const int32_t* lane_cell;
+    // sticky status word of the handle (device memory, zero = healthy): bit 0 = a tail role of the step kernel gave up
+    // waiting for its group's integrating wave (dockauv_step.hip.inc: wait_nav_).  Read by the host wherever it
+    // synchronises with the stream anyway; reported as DOCKAUV_E_KERNEL.
+    unsigned int* status;
     long stride;
 };
 
@@ -190,6 +194,7 @@ int launch_step_f64(const KernelArgs<double, 2>& a, int vk, bool sym, bool has_r
 
 #ifdef DOCKAUV_STAMPS
 int read_stamps(unsigned long long* out);   // diagnostic build only
+int read_span(unsigned long long* out, int groups);
 #endif
 
 }  // namespace dockauv

@@ -39,6 +39,10 @@ extern "C" {
 #define DOCKAUV_E_HIP (-2)       /* HIP runtime error (message has hipGetErrorString) */
 #define DOCKAUV_E_NODEVICE (-3)  /* no usable gfx950 device */
 #define DOCKAUV_E_RANGE (-4)     /* first/count outside [0, n_envs) */
+#define DOCKAUV_E_KERNEL (-5)    /* a step kernel reported an internal time-out in the handle's sticky status word (an
+                                    intra-group wait gave up instead of hanging the GPU); reported by the calls that
+                                    synchronise: dockauv_synchronize, dockauv_get_field, dockauv_step_host,
+                                    dockauv_time_steps, dockauv_trace_read.  Results since are invalid. */
 
 /* device arithmetic type of the path */
 #define DOCKAUV_F32 0            /* product path ("within 1e-5 of the float64 reference") */

@@ -426,13 +426,40 @@ def episode_record(env):
     )
 
 
-def run_traj(name, env_name, vehicle, seed, T, controller, cfg_over=None, act_seed=1):
+def place_near_obstacle(rs, dist=(4.0, 6.0)):
+    """Episode hook: after the reference's own reset, move the vehicle to 4-6 m from the axis of one of the env's
+    capsules, roughly at the goal's depth and facing the capsule (+-0.25 rad), through the reference's own setters
+    (objects/auvsim.py:174-195) -- where a docking policy spends its steps: the goal sits ON the centre capsule's
+    safety surface (docking3d.py:868-876), so an approach has the fan full of hits.  Positions closer than 2.6 m to
+    any capsule axis are redrawn (no collision at t = 0)."""
+    def f(env):
+        caps = env.capsules
+        axes = [0.5 * (np.asarray(c.vec_top, float) + np.asarray(c.vec_bot, float))[:2] for c in caps]
+        for _ in range(1000):
+            k = rs.randint(len(caps))
+            ang, d = rs.uniform(-np.pi, np.pi), rs.uniform(*dist)
+            pos = np.array([axes[k][0] + d * np.cos(ang), axes[k][1] + d * np.sin(ang),
+                            env.goal_location[2] + rs.uniform(-1.0, 1.0)])
+            if min(np.linalg.norm(pos[:2] - a) for a in axes) >= 2.6 and np.linalg.norm(pos - env.goal_location) < 15.0:
+                break
+        else:
+            raise RuntimeError("no free position found")
+        heading = np.arctan2(axes[k][1] - pos[1], axes[k][0] - pos[0]) + rs.uniform(-0.25, 0.25)
+        env.auv.position = pos
+        env.auv.attitude = np.array([rs.uniform(-0.1, 0.1), rs.uniform(-0.15, 0.15), geom.ssa(heading)])
+    return f
+
+
+def run_traj(name, env_name, vehicle, seed, T, controller, cfg_over=None, act_seed=1, post_reset=None):
     cfg = make_cfg(vehicle=vehicle, **(cfg_over or {}))
     env = ENV_CLASSES[env_name](cfg)
     rs = np.random.RandomState(act_seed)
     ctrl = controller(rs)
     obs0 = env.reset(seed=seed)
     assert np.all(obs0 == 0)
+    drawn = [np.concatenate([env.auv.position, env.auv.attitude])]   # the reference's own reset draw (G8)
+    if post_reset:
+        post_reset(env)
     n_u = env.auv.u_bound.shape[0]
     R = env.radar.n_rays
     rec = {k: [] for k in ("action", "state", "u", "nu_c", "V_c", "euler_dot", "obs", "reward", "reward_arr",
@@ -465,6 +492,9 @@ def run_traj(name, env_name, vehicle, seed, T, controller, cfg_over=None, act_se
         n_goal += int(env.conditions[0])
         if done and t + 1 < T:
             env.reset()                      # no seed: the global stream continues (burned by per-step normals)
+            drawn.append(np.concatenate([env.auv.position, env.auv.attitude]))
+            if post_reset:
+                post_reset(env)
             episodes.append(episode_record(env))
             ep_start.append(t + 1)
     arrays = {k: np.array(v) for k, v in rec.items()}
@@ -475,6 +505,8 @@ def run_traj(name, env_name, vehicle, seed, T, controller, cfg_over=None, act_se
     arrays["ep_attitude"] = np.array([e["attitude"] for e in episodes])
     arrays["ep_goal"] = np.array([e["goal"] for e in episodes])
     arrays["ep_heading_goal"] = np.array([e["heading_goal"] for e in episodes])
+    if post_reset:   # pose the reference drew before the hook moved the vehicle (ep_position / ep_attitude = after)
+        arrays["ep_pose_drawn"] = np.array(drawn)
     arrays["ep_current"] = np.array([e["current"] for e in episodes])
     caps = np.zeros((E, n_cap_max, 7))
     ncap = np.zeros(E, dtype=np.int64)
@@ -493,8 +525,10 @@ def run_traj(name, env_name, vehicle, seed, T, controller, cfg_over=None, act_se
     for k, v in meta.items():
         arrays["meta_" + k] = np.array(v)
     conds = arrays["conditions"].sum(axis=0)
+    in_range = arrays["ray_dist"] < float(cfg["radar"]["max_dist"])
     print(f"  {name}: episodes={E} cond counts goal/out/att/maxt/col={conds.tolist()} "
-          f"min_ray={arrays['ray_dist'].min():.3f}")
+          f"min_ray={arrays['ray_dist'].min():.3f} rays in range: {in_range.mean():.3f} of all rays, "
+          f"{in_range.any(axis=1).mean():.3f} of the steps")
     save(name, **arrays)
     return arrays
 
@@ -535,6 +569,7 @@ def gen_trajectories():
     run_traj("traj_ObstaclesCurrentDocking3d_lauv_random", "ObstaclesCurrentDocking3d", "LAUV", 63, 200,
              lambda rs: ctrl_random(rs), cfg_over=dict(lauv, max_timesteps=90), act_seed=14)
     gen_mixed_partner()
+    gen_near_obstacles()
 
 
 def gen_mixed_partner():
@@ -543,6 +578,21 @@ def gen_mixed_partner():
     the reference (tests/test_gpu_fullsize.py)."""
     run_traj("traj_ObstaclesCurrentDocking3d_bluerov2_h002_random", "ObstaclesCurrentDocking3d", "BlueROV2", 64, 200,
              lambda rs: ctrl_random(rs), cfg_over={"t_step_size": 0.02, "max_timesteps": 90}, act_seed=15)
+
+
+def gen_near_obstacles():
+    """Round 3: LAUV (config 4) and the mixed pair (config 5) with the fan full of hits -- the two LAUV obstacle
+    trajectories above never have a ray in range (min_ray = 10.0).  Vehicles start 4-6 m from a capsule, facing it."""
+    near = {"t_step_size": 0.02, "max_timesteps": 90}
+    run_traj("traj_ObstaclesDocking3d_lauv_near", "ObstaclesDocking3d", "LAUV", 71, 450,
+             lambda rs: ctrl_goto(rs, noise=0.3), cfg_over=dict(near, max_timesteps=220), act_seed=16,
+             post_reset=place_near_obstacle(np.random.RandomState(171)))
+    run_traj("traj_ObstaclesCurrentDocking3d_lauv_near", "ObstaclesCurrentDocking3d", "LAUV", 72, 240,
+             lambda rs: ctrl_goto(rs, noise=0.3), cfg_over=near, act_seed=17,
+             post_reset=place_near_obstacle(np.random.RandomState(172)))
+    run_traj("traj_ObstaclesCurrentDocking3d_bluerov2_h002_near", "ObstaclesCurrentDocking3d", "BlueROV2", 73, 240,
+             lambda rs: ctrl_goto(rs, noise=0.3), cfg_over=near, act_seed=18,
+             post_reset=place_near_obstacle(np.random.RandomState(173)))
 
 
 def gen_radar_layout():
@@ -574,6 +624,9 @@ if __name__ == "__main__":
     print("reference:", REF)
     if "--mixed-partner-only" in sys.argv:    # added in round 2; the other fixtures are unchanged
         gen_mixed_partner()
+        sys.exit(0)
+    if "--near-only" in sys.argv:             # added in round 3; the other fixtures are unchanged
+        gen_near_obstacles()
         sys.exit(0)
     gen_constants()
     gen_state_dot()

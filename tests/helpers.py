@@ -134,6 +134,64 @@ def load_teacher_forced(env, inp):
     env.set_field(_capi.F_TSTEPS, inp["tsteps"][:, None].astype(float))
 
 
+# share of a trajectory's steps whose ray-dependent entries (ray cells, obstacle-avoidance term, total reward) may miss the
+# tolerance because the step contains a float32 ray outlier; asserted and printed per trajectory
+MAX_EXCLUDED = 0.01
+
+
+def justified_done_flips(env, done, gold, precision, name):
+    """`done` must equal the reference's EXACTLY, except for the envs enumerated here: a flip is accepted only where the
+    reference itself sits within 10 * tol["state"] of the threshold of a distance / attitude condition
+    (docking3d.py:608-612).  A flip of the time limit or of the collision flag is never accepted.  Returns the indices
+    of the accepted flips."""
+    tol = TOL[precision]
+    dtol, dmax, matt = (float(env.config[k]) for k in ("dist_goal_reached_tol", "max_dist_from_goal", "max_attitude"))
+    flips = np.flatnonzero(np.asarray(done, bool) != np.asarray(gold["done"], bool))
+    for j in flips:
+        dd = gold["nav"][j, 0]
+        near = min(abs(dd - dtol), abs(dd - dmax), np.min(np.abs(np.abs(gold["state"][j, 3:5]) - matt)))
+        assert near < 10 * tol["state"], (f"{name}: done differs at env {j} (ours {bool(done[j])}, reference "
+                                          f"{bool(gold['done'][j])}) and no threshold is within {10 * tol['state']:.1e}: "
+                                          f"delta_d {dd}, attitude {gold['state'][j, 3:5]}, conditions {gold['conditions'][j]}")
+        assert not (gold["conditions"][j, 3] or gold["conditions"][j, 4]), f"{name}: time-limit / collision flip at env {j}"
+    assert flips.size <= max(1, int(1e-3 * len(done))), f"{name}: {flips.size} done flips"
+    return flips
+
+
+def compare_obs_reward(obs, rew, terms, gold, step_has_ray_outlier, precision, name, rew_floor=0.0):
+    """Observation rows and rewards of every env against its golden step.  NO step is left out:
+      * obs[:16] and the twelve reward terms that do not depend on the rays: every step within tolerance (obs[2] =
+        delta_psi / pi lives on a circle and is compared modulo 2: a step at the wrap is checked like any other; its
+        reward term is even in delta_psi and continuous there);
+      * the ray cells obs[16:], the obstacle-avoidance term and the total reward: within tolerance as well, except in
+        steps that contain a float32 ray outlier (a hit at grazing incidence has unbounded condition number: d ~ sqrt(h),
+        h -> 0; the caller bounds their number and size) -- every violation must sit in such a step, and the share of
+        those steps is bounded by MAX_EXCLUDED.
+    terms may be None (product kernel: no per-term output); rew_floor: lower bound of the reward tolerances (a packed
+    row carries the reward as float32)."""
+    tol = dict(TOL[precision])
+    tol["rew_rel"], tol["rew_abs"] = max(tol["rew_rel"], rew_floor), max(tol["rew_abs"], rew_floor)
+    d = np.abs(obs.astype(np.float64) - gold["obs"])
+    d[:, 2] = np.minimum(d[:, 2], np.abs(2.0 - d[:, 2]))
+    assert d[:, :16].max() <= tol["obs"], f"{name}: max |obs[:16] - ref| = {d[:, :16].max():.3e} at {np.unravel_index(d[:, :16].argmax(), d[:, :16].shape)}"
+    cell_viol = (d[:, 16:] > tol["obs"]).any(axis=1)
+
+    def beyond(a, b, rtol, atol):
+        return np.abs(a - b) > atol + rtol * np.abs(b)
+    rew_viol = beyond(np.asarray(rew, np.float64), gold["reward"], tol["rew_rel"], tol["rew_abs"])
+    if terms is not None:
+        tv = beyond(terms, gold["reward_arr"], tol["rew_rel"], tol["rew_abs"])
+        other = [k for k in range(terms.shape[1]) if k != 6]
+        assert not tv[:, other].any(), f"{name}: reward terms {np.argwhere(tv[:, other])[:4].tolist()} differ"
+        rew_viol |= tv[:, 6]
+    viol = cell_viol | rew_viol
+    assert not (viol & ~step_has_ray_outlier).any(), (f"{name}: ray cells / reward beyond tolerance in steps without a ray outlier: "
+                                                      f"{np.flatnonzero(viol & ~step_has_ray_outlier)[:8].tolist()}")
+    assert float(viol.mean()) <= MAX_EXCLUDED, f"{name}: {viol.mean():.4f} of the steps have a ray-dependent entry beyond tolerance"
+    ok = ~viol
+    return dict(share=float(viol.mean()), obs16=float(d[:, :16].max()), rew=float(np.abs(np.asarray(rew)[ok] - gold["reward"][ok]).max()))
+
+
 def check_teacher_forced(env, obs, rew, done, gold, precision, name):
     """Every env against the golden step it was started from (rules: tests/test_gpu_parity.py docstring)."""
     from gym_dockauv_amd import _capi
@@ -147,8 +205,8 @@ def check_teacher_forced(env, obs, rew, done, gold, precision, name):
         np.testing.assert_allclose(new_u[m][:, :n_u], gold["u"][m][:, :n_u], rtol=0, atol=tol["state"], err_msg=name)
     np.testing.assert_allclose(env.get_field(_capi.F_CURRENT)[:, 0], gold["V_c"], rtol=0, atol=tol["state"])
     # rays: a hit at grazing incidence has unbounded condition number (d ~ sqrt(h), h -> 0), so the float32 path
-    # may flip a handful of hit/miss decisions; everything else must be within tol.  Steps that contain such a
-    # ray are excluded from the obs / reward comparison below (the ray feeds both), and their share is bounded.
+    # may flip a handful of hit/miss decisions; everything else must be within tol.  A step that contains such a
+    # ray may miss the tolerance in its ray cells / obstacle-avoidance reward (only there, compare_obs_reward).
     ray_err = np.abs(env.intersec_dist - gold["ray_dist"])
     ray_bad = ray_err > tol["ray"]
     if precision == "f64":
@@ -159,16 +217,11 @@ def check_teacher_forced(env, obs, rew, done, gold, precision, name):
         both_hit = ray_bad & (env.intersec_dist < env.radar.max_dist) & (gold["ray_dist"] < env.radar.max_dist)
         if both_hit.any():
             assert ray_err[both_hit].max() < 1e-2, name
-    step_ok = ~ray_bad.any(axis=1)
     nav = env.nav_errors
     np.testing.assert_allclose(nav[:, 0], gold["nav"][:, 0], rtol=0, atol=tol["nav"], err_msg=name)
     assert angle_diff(nav[:, 1:], gold["nav"][:, 1:]).max() <= tol["nav"], name
-    # observations: psi-derived entries jump at the wrap; everything else direct
-    wrap = (np.abs(np.abs(gold["nav"][:, 2]) - np.pi) < 1e-3) | ~step_ok
-    np.testing.assert_allclose(obs[~wrap], gold["obs"][~wrap], rtol=0, atol=tol["obs"], err_msg=name)
     terms = env.last_reward_arr
-    np.testing.assert_allclose(terms[~wrap], gold["reward_arr"][~wrap], rtol=tol["rew_rel"], atol=tol["rew_abs"], err_msg=name)
-    np.testing.assert_allclose(rew[~wrap], gold["reward"][~wrap], rtol=tol["rew_rel"], atol=tol["rew_abs"], err_msg=name)
+    excluded = compare_obs_reward(obs, rew, terms, gold, ray_bad.any(axis=1), precision, name)
     # conditions are threshold tests: allow a flip only when the reference sits within tol of the threshold
     cond = env.conditions
     for t, k in np.argwhere(cond != gold["conditions"]):
@@ -176,10 +229,15 @@ def check_teacher_forced(env, obs, rew, done, gold, precision, name):
         near = {0: abs(dd - 0.5), 1: abs(dd - 20.0),
                 2: np.min(np.abs(np.abs(gold["state"][t, 3:5]) - np.pi / 3))}.get(int(k), 1.0)
         assert near < 10 * tol["state"], f"{name}: condition {k} differs at env {t}"
-    assert (done == gold["done"]).mean() > 0.99
+    # done: exact, but for the enumerated threshold cases -- and those must be the envs whose condition bits flipped
+    flips = justified_done_flips(env, done, gold, precision, name)
+    assert set(flips.tolist()) <= set(np.flatnonzero((cond != gold["conditions"]).any(axis=1)).tolist()), name
+    assert np.array_equal(np.asarray(done, bool), cond.any(axis=1)), f"{name}: done is not the OR of the condition bits"
     assert np.array_equal(env.t_steps, gold["t_steps"])
-    return dict(obs=float(np.abs(obs[~wrap] - gold["obs"][~wrap]).max()), rew=float(np.abs(rew[~wrap] - gold["reward"][~wrap]).max()),
-                excluded=float(wrap.mean()))
+    print(f"[parity {precision}] {name}: steps with a ray-dependent entry beyond tolerance (each one has a ray outlier): "
+          f"{excluded['share']:.4f}; steps with a ray outlier {float(ray_bad.any(axis=1).mean()):.4f}; done flips {flips.size}; "
+          f"rays in range {float((gold['ray_dist'] < env.radar.max_dist).mean()):.3f}; max |obs[:16] - ref| {excluded['obs16']:.2e}")
+    return dict(obs=excluded["obs16"], rew=excluded["rew"], excluded=excluded["share"], done_flips=int(flips.size))
 
 
 # ------------------------------------------------------------------------------------------------ product (lean) kernels
