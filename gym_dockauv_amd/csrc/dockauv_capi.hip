@@ -440,7 +440,7 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
         return rc;                                         \
     }
     ALLOC(B.state, 12 * S * t);
-    ALLOC(B.pos_lo, 3 * S * t);
+    ALLOC(B.pos_lo, kLoRows * S * t);
     ALLOC(B.u, kMaxU * S * t);
     ALLOC(B.goal, 4 * S * t);
     ALLOC(B.cur, 8 * S * t);
@@ -617,15 +617,15 @@ int dockauv_set_field(dockauv_handle h, int field, int first, int count, const d
     unsigned char* dst = static_cast<unsigned char*>(fd.base) + (size_t)first * es;
     HIP_TRY(h, hipMemcpy2D(dst, (size_t)h->S * es, tmp.data(), (size_t)count * es, (size_t)count * es, fd.rows, hipMemcpyHostToDevice));
     if (field == DOCKAUV_F_STATE) {
-        // low-order words of the position (float path: what the float32 state rows cannot hold of the float64 input)
-        std::vector<unsigned char> lo((size_t)3 * count * es);
+        // low-order words of position and heading (float path: what the float32 state rows cannot hold of the float64 input)
+        std::vector<unsigned char> lo((size_t)kLoRows * count * es);
         for (int i = 0; i < count; ++i)
-            for (int k = 0; k < 3; ++k) {
-                const double x = src[(size_t)i * width + k];
+            for (int k = 0; k < kLoRows; ++k) {
+                const double x = src[(size_t)i * width + kLoState[k]];
                 store_elem(h, 0, lo.data(), (size_t)k * count + i, h->f64 ? 0.0 : x - (double)(float)x);
             }
         unsigned char* dlo = static_cast<unsigned char*>(h->B.pos_lo) + (size_t)first * es;
-        HIP_TRY(h, hipMemcpy2D(dlo, (size_t)h->S * es, lo.data(), (size_t)count * es, (size_t)count * es, 3, hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy2D(dlo, (size_t)h->S * es, lo.data(), (size_t)count * es, (size_t)count * es, kLoRows, hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -653,12 +653,12 @@ int dockauv_get_field(dockauv_handle h, int field, int first, int count, double*
         for (int i = 0; i < count; ++i)
             for (int k = 0; k < width; ++k) dst[(size_t)i * width + k] = load_elem(h, fd.kind, tmp.data(), (size_t)k * count + i);
     }
-    if (field == DOCKAUV_F_STATE && !h->f64) {   // position = state[0:3] + pos_lo
-        std::vector<unsigned char> lo((size_t)3 * count * es);
+    if (field == DOCKAUV_F_STATE && !h->f64) {   // position, heading = their state rows + pos_lo
+        std::vector<unsigned char> lo((size_t)kLoRows * count * es);
         const unsigned char* slo = static_cast<const unsigned char*>(h->B.pos_lo) + (size_t)first * es;
-        HIP_TRY(h, hipMemcpy2D(lo.data(), (size_t)count * es, slo, (size_t)h->S * es, (size_t)count * es, 3, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy2D(lo.data(), (size_t)count * es, slo, (size_t)h->S * es, (size_t)count * es, kLoRows, hipMemcpyDeviceToHost));
         for (int i = 0; i < count; ++i)
-            for (int k = 0; k < 3; ++k) dst[(size_t)i * width + k] += load_elem(h, 0, lo.data(), (size_t)k * count + i);
+            for (int k = 0; k < kLoRows; ++k) dst[(size_t)i * width + kLoState[k]] += load_elem(h, 0, lo.data(), (size_t)k * count + i);
     }
     return 0;
 }
@@ -671,7 +671,7 @@ int dockauv_reset_envs(dockauv_handle h, int first, int count) {
     if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream)); else HIP_TRY(h, hipDeviceSynchronize());
     const size_t t = h->tsz, S = (size_t)h->S;
     HIP_TRY(h, hipMemset2D(static_cast<unsigned char*>(h->B.state) + first * t, S * t, 0, count * t, 12));
-    HIP_TRY(h, hipMemset2D(static_cast<unsigned char*>(h->B.pos_lo) + first * t, S * t, 0, count * t, 3));
+    HIP_TRY(h, hipMemset2D(static_cast<unsigned char*>(h->B.pos_lo) + first * t, S * t, 0, count * t, kLoRows));
     HIP_TRY(h, hipMemset2D(static_cast<unsigned char*>(h->B.u) + first * t, S * t, 0, count * t, kMaxU));
     HIP_TRY(h, hipMemset(static_cast<unsigned char*>(h->B.cum_reward) + first * t, 0, count * t));
     HIP_TRY(h, hipMemset(h->B.t_steps + first, 0, count * 4));

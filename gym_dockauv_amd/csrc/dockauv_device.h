@@ -8,6 +8,8 @@ namespace dockauv {
 
 constexpr int kMaxU = 8;
 constexpr int kNRew = 13;
+constexpr int kLoRows = 4;                       // rows of Buffers::pos_lo
+constexpr int kLoState[kLoRows] = {0, 1, 2, 5};  // the state rows they belong to
 
 // indices into VehicleP::lauv (same order as dockauv_vehicle::lauv in include/dockauv.h)
 enum LauvIdx {
@@ -65,7 +67,8 @@ struct EnvP {
 // rounded up to a multiple of 64 so that every row starts 256-B aligned.
 struct Buffers {
     void* state;      // T [12][S]
-    void* pos_lo;     // T [3][S]   low-order words of the position (compensated accumulation: position = state[0:3] + pos_lo)
+    void* pos_lo;     // T [4][S]   low-order words of the position and of the heading (compensated accumulation, float
+                      //            path: x y z psi = state[{0, 1, 2, 5}] + pos_lo[{0, 1, 2, 3}]; zero in float64)
     void* u;          // T [kMaxU][S]
     void* goal;       // T [4][S]   x y z heading
     void* cur;        // T [6][S]   V_c, dir_x, dir_y, dir_z (NED unit vector), V_min, V_max

@@ -4,7 +4,7 @@ from tests import helpers as H
 
 
 def main():
-    print(f"{'trajectory':58s} {'obs':>9s} {'obs(noray)':>10s} {'rew_rel':>9s} {'r6_abs':>9s} {'state':>9s} {'badrays':>7s}")
+    print(f"{'trajectory':58s} {'obs':>9s} {'obs(noray)':>10s} {'rew_rel':>9s} {'r6_abs':>9s} {'state':>9s} {'pos':>9s} {'att':>9s} {'vel':>9s} {'angvel':>9s} {'badrays':>7s}")
     for name in H.TRAJ:
         g = H.load(name)
         T, n_u = int(g["meta_T"]), int(g["meta_n_u"])
@@ -13,6 +13,7 @@ def main():
         ep_start = g["ep_start"].tolist()
         e = -1
         wo = wo2 = wr = w6 = ws = 0.0
+        wp = wa = wv = wq = 0.0
         bad = 0
         for t in range(T):
             if t in ep_start:
@@ -31,8 +32,12 @@ def main():
             w6 = max(w6, abs(float(env.last_reward_arr[0, 6]) - g["reward_arr"][t, 6]))
             st = env.state[0]
             ws = max(ws, float(np.abs(st[[0, 1, 2, 6, 7, 8, 9, 10, 11]] - g["state"][t][[0, 1, 2, 6, 7, 8, 9, 10, 11]]).max()))
+            wp = max(wp, float(np.abs(st[0:3] - g["state"][t][0:3]).max()))
+            wa = max(wa, float(H.angle_diff(st[3:6], g["state"][t][3:6]).max()))
+            wv = max(wv, float(np.abs(st[6:9] - g["state"][t][6:9]).max()))
+            wq = max(wq, float(np.abs(st[9:12] - g["state"][t][9:12]).max()))
         env.close()
-        print(f"{name:58s} {wo:9.2e} {wo2:10.2e} {wr:9.2e} {w6:9.2e} {ws:9.2e} {bad:7d}")
+        print(f"{name:58s} {wo:9.2e} {wo2:10.2e} {wr:9.2e} {w6:9.2e} {ws:9.2e} {wp:9.2e} {wa:9.2e} {wv:9.2e} {wq:9.2e} {bad:7d}")
 
 
 if __name__ == "__main__":
