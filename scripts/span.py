@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=3)
 ap.add_argument("--envs", type=int, default=0)
 ap.add_argument("--threads", type=int, default=0)
+ap.add_argument("--queued", type=int, default=1, help="launches queued back to back before the one that is read (1 = an isolated launch)")
 args = ap.parse_args()
 wl = bench.workload(args.config, args.envs)
 N = wl["envs"]
@@ -35,25 +36,29 @@ for it in range(300):   # into the steady state of the episodes
 torch.cuda.synchronize()
 runs = []
 for it in range(40):
-    # event-timed like bench.py: dockauv_time_steps on this very launch
-    us = env.time_steps_device(a[it % 8].data_ptr(), out.data_ptr(), steps=1, stream=stream, packed=True)
+    # event-timed like bench.py: dockauv_time_steps on this very launch (the last of --queued back-to-back ones)
+    # (--queued K: K launches queued by ONE C call, dockauv_time_steps, i.e. truly back to back on the stream -- launches
+    # issued from Python arrive ~10 us apart and the GPU idles in between; `us` = their average event-timed duration)
+    us = env.time_steps_device(a[it % 8].data_ptr(), out.data_ptr(), steps=args.queued, stream=stream, packed=True)
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * (4 * G))()
+    buf = (ctypes.c_ulonglong * (6 * G))()
     rc = lib.dockauv_debug_read_span(buf, G)
     assert rc == 0, rc
-    runs.append((us, np.frombuffer(buf, dtype=np.uint64).reshape(G, 4).astype(np.int64).copy()))
+    runs.append((us, np.frombuffer(buf, dtype=np.uint64).reshape(G, 6).astype(np.int64).copy()))
 ev = np.array([r[0] for r in runs])
-sp = np.stack([r[1] for r in runs])          # [launch, group, (rt0, t0, rt1, t1)]
-rt0, t0, rt1, t1 = (sp[:, :, k].astype(np.float64) for k in range(4))
+sp = np.stack([r[1] for r in runs])          # [launch, group, (rt, t) at entry / after the first kernarg + parameter words / end]
+rt0, t0, rta, ta, rt1, t1 = (sp[:, :, k].astype(np.float64) for k in range(6))
+arg_us = (rta - rt0) / 100.0
 first = rt0.min(axis=1, keepdims=True)
 start_us = (rt0 - first) / 100.0
 end_us = (rt1 - first) / 100.0
 life_ticks = t1 - t0
 life_us = (rt1 - rt0) / 100.0
-print(f"{wl['name']}  N={N}  groups={G}  (median over {len(runs)} launches; 100 MHz clock: +-0.01 us)")
+print(f"{wl['name']}  N={N}  groups={G}  (median over {len(runs)} launches, each the last of {args.queued} queued back to back; 100 MHz clock: +-0.01 us)")
 print(f"  event-timed duration of these launches        : {np.nanmedian(ev):6.2f} us")
 print(f"  first group start -> last group end           : {np.median(end_us.max(axis=1)):6.2f} us")
 print(f"  first group start -> last group START (ramp)  : {np.median(start_us.max(axis=1)):6.2f} us   (p50 of the starts {np.median(np.median(start_us, axis=1)):.2f}, p90 {np.median(np.percentile(start_us, 90, axis=1)):.2f})")
+print(f"  entry -> first kernarg / parameter words there: median {np.median(arg_us):.2f} us, p90 {np.median(np.percentile(arg_us, 90, axis=1)):.2f}, max {np.median(arg_us.max(axis=1)):.2f}")
 print(f"  group life: median {np.median(life_us):.2f} us = {np.median(life_ticks):.0f} ticks  ({np.median(life_ticks) / np.median(life_us) / 1000:.3f} ticks/ns);"
       f"  p90 {np.median(np.percentile(life_us, 90, axis=1)):.2f}  p99 {np.median(np.percentile(life_us, 99, axis=1)):.2f}  max {np.median(life_us.max(axis=1)):.2f} us")
 print(f"  first group END {np.median(end_us.min(axis=1)):.2f} us, median END {np.median(np.median(end_us, axis=1)):.2f}, p90 {np.median(np.percentile(end_us, 90, axis=1)):.2f}, last {np.median(end_us.max(axis=1)):.2f}")
@@ -64,5 +69,5 @@ for k in range(8):
     print(f"    groups {sl.start:5d}..{sl.stop - 1:5d}: start {np.median(start_us[:, sl]):5.2f}  life {np.median(life_us[:, sl]):5.2f}  end {np.median(end_us[:, sl]):5.2f}   max end {np.median(end_us[:, sl].max(axis=1)):5.2f}")
 print("  by XCD (group % 8): start / life / end")
 for x in range(8):
-    print(f"    xcd {x}: start {np.median(start_us[:, x::8]):5.2f}  life {np.median(life_us[:, x::8]):5.2f}  max end {np.median(end_us[:, x::8].max(axis=1)):5.2f}")
+    print(f"    xcd {x}: start {np.median(start_us[:, x::8]):5.2f}  kernarg+params after {np.median(arg_us[:, x::8]):5.2f}  life {np.median(life_us[:, x::8]):5.2f}  max end {np.median(end_us[:, x::8].max(axis=1)):5.2f}")
 env.close()
