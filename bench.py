@@ -44,7 +44,7 @@ VALU_CYCLES_PER_INST = 4.0                       # issue slots a wave64 VALU ins
 VALU_CYCLES_MEASURED = 2.1                       # plain fp32 VALU instruction on a saturated SIMD, measured (scripts/micro/issue_rate.hip)
 
 
-def workload(config_id: int, envs: int):
+def workload(config_id: int, envs: int, layout: str = ""):
     from gym_dockauv_amd.config.env_config import BASE_CONFIG
     cfg = copy.deepcopy(BASE_CONFIG)
     fan16 = {"alpha": 30 * np.pi / 180, "beta": 30 * np.pi / 180, "ray_per_deg": 10 * np.pi / 180}
@@ -63,7 +63,7 @@ def workload(config_id: int, envs: int):
     if config_id == 5:
         cfg["t_step_size"] = 0.02
         n = envs or 65536
-        if os.environ.get("DOCKAUV_CONFIG5_SORTED") == "1":
+        if layout == "vehicle_sorted" or (not layout and os.environ.get("DOCKAUV_CONFIG5_SORTED") == "1"):
             # vehicle-sorted layout: first half BlueROV2, second half LAUV -> every wave but one is homogeneous
             return dict(id=5, cfg=cfg, scenario="ObstaclesCurrentDocking3d", envs=n, current_speed="uniform01",
                         vehicles=["BlueROV2"] * (n // 2) + ["LAUV"] * (n - n // 2),
@@ -76,14 +76,19 @@ def workload(config_id: int, envs: int):
 
 def kernel_source_sha() -> str:
     """Identifies the kernel version a profile under profiles/ belongs to: a hash of the device sources without their
-    comments and blank lines (a comment edit does not make the committed counters stale)."""
+    comments (// and /* */, string literals respected) and blank lines (a comment edit does not make the committed
+    counters stale)."""
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "gym_dockauv_amd", "csrc")
+    pat = re.compile(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\])*"|\'(?:\\.|[^\'\\])*\'', re.S)
     for f in sorted(os.listdir(d)):
         if f.endswith((".hip", ".inc", ".h")):
-            for line in open(os.path.join(d, f), encoding="utf-8", errors="replace"):
-                code = line.split("//", 1)[0].rstrip()
-                if code:
+            text = open(os.path.join(d, f), encoding="utf-8", errors="replace").read()
+            text = pat.sub(lambda m: m.group(0) if m.group(0)[0] in "\"'" else " ", text)
+            for line in text.splitlines():
+                code = line.rstrip()
+                if code.strip():
                     h.update(code.encode() + b"\n")
     return h.hexdigest()[:12]
 
@@ -181,10 +186,26 @@ def make_env(wl, local_rank: int, rank: int, threads: int):
     return env
 
 
-def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha: str):
+# What limits each BASELINE workload at its batch size: the figure reported is always the
+# algorithmic-bytes fraction of the HBM peak (the contract's `achieved` / `peak`), `bound` says what the launch is really
+# waiting for.  "hbm": streaming bound.  "valu": above the ridge (~48 FLOP/B for the 63-ray fan), the ray stage's
+# arithmetic at 4 waves per SIMD.  "latency": every group of the launch is resident at once and the launch lasts as long
+# as ONE group's dependent instruction stream (a lone integrating wave per SIMD).  "launch": fewer waves than SIMDs; the
+# event-timed duration sits on the floor of an empty dispatch (profiles/r2/launch_floor.txt: 3.96 us).
+def bound_of(config_id: int, envs: int, dense: bool = False) -> str:
+    if envs <= 8192:
+        return "launch"
+    if envs > 262144:
+        return "hbm" if config_id == 2 else "latency"     # (ray kernels: LDS-limited residency x group latency)
+    if dense and config_id in (4, 5):
+        return "valu"
+    return "latency"
+
+
+def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha: str, dense: bool = False):
     bytes_per_launch = ALGO_BYTES[config_id] * envs
     achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
-    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+    r = {"bound": "hbm", "limited_by": bound_of(config_id, envs, dense), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
          "traffic": None, "kernel": "dockauv::step_kernel", "kernel_us": kernel_us,
          "algorithmic_bytes_per_env_step": ALGO_BYTES[config_id], "envs_per_launch": envs,
          "timing": f"hipExtLaunchKernel start/stop events on the launch stream, {n_timed} launches"}
@@ -197,6 +218,8 @@ def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha:
         if e.get("traffic_bytes"):
             r["traffic_over_algorithmic"] = e["traffic_bytes"] / bytes_per_launch
         if e.get("sq_insts_valu"):
+            if stale:
+                r["valu_frac_note"] = "SQ_INSTS_VALU was counted on an earlier kernel version than this library: indicative only"
             cyc = kernel_us * CLOCK_MHZ
             r["valu_frac"] = e["sq_insts_valu"] * VALU_CYCLES_PER_INST / (N_SIMD * cyc)
             # the same count priced at what a saturated SIMD was MEASURED to need for a plain fp32 instruction
@@ -270,9 +293,101 @@ def closed_loop_rate(env, torch, dev, N, n_obs, n_u, steps):
     return res
 
 
-def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, kernel_launches=512):
+def place_ray_dense(env, rng):
+    """Every env within sensor range of one of its obstacles and facing it (host set_field): 3-5 m from the surface of its
+    first sphere, or from the axis-parallel surface of its first capsule, at the obstacle's depth, heading towards it
+    (+- 0.1 rad), at rest.  Where a docking policy lives: the goal sits ON the centre capsule's safety surface
+    (envs/docking3d.py:868-876)."""
+    from gym_dockauv_amd import _capi
+    N = env.num_envs
+    ang = rng.uniform(-np.pi, np.pi, N)
+    if env.max_spheres:
+        sph = env.get_field(_capi.F_SPHERES).reshape(N, -1, 4)
+        centre, rad = sph[:, 0, 0:3], sph[:, 0, 3]
+    else:
+        caps = env.get_field(_capi.F_CAPSULES).reshape(N, -1, 7)
+        centre = 0.5 * (caps[:, 0, 0:3] + caps[:, 0, 3:6])
+        centre[:, 2] += rng.uniform(-1.0, 1.0, N)
+        rad = caps[:, 0, 6]
+    d = rad + rng.uniform(3.0, 5.0, N)
+    state = np.zeros((N, 12))
+    state[:, 0] = centre[:, 0] - d * np.cos(ang)
+    state[:, 1] = centre[:, 1] - d * np.sin(ang)
+    state[:, 2] = centre[:, 2]
+    psi = ang + rng.uniform(-0.1, 0.1, N)
+    state[:, 5] = (psi + np.pi) % (2 * np.pi) - np.pi
+    env.set_field(_capi.F_STATE, state)
+    env.set_field(_capi.F_U, np.zeros((N, 8)))
+    env.set_field(_capi.F_TSTEPS, np.zeros((N, 1)))
+
+
+def measure_ray_dense(config_id, args, torch, dev, local_rank, rank, ksha):
+    """The ray stage where it is busy: under uniform random actions 84-99 % of the envs have no obstacle
+    within reach of the fan and take no ray pass at all (profiles/r2/active_fraction.txt).  Here every env sits 3-5 m in
+    front of an obstacle and holds its position (BlueROV2: the heave input that cancels its 1.985 N of buoyancy, LAUV:
+    zero inputs; no reset; vehicles are put back before every timed region), so that >= 90 % of the fans have a hit."""
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    wl = workload(config_id, 0)
+    N = wl["envs"]
+    env = BatchedDocking3d(wl["cfg"], num_envs=N, scenario=wl["scenario"], device=local_rank, precision="f32",
+                           reset_mode="none", rng="batched", vehicles=wl["vehicles"], threads_per_group=args.threads)
+    env._gen = np.random.default_rng(2000 + rank)
+    env.reset()
+    rng = np.random.default_rng(3000 + rank)
+    n_obs, n_u = env.n_observations, env.n_u
+    hold = torch.zeros((N, n_u), device=dev, dtype=torch.float32)
+    if wl["cfg"]["vehicle"] == "BlueROV2":
+        hold[:, 2] = 1.985 / 80.0     # W - B = -1.985 N (Q14); heave gain 4 x 20 N per unit input (BlueROV2.py:34-51)
+    out = torch.zeros((N, n_obs + 2), device=dev, dtype=torch.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    K = min(args.steps, 250)
+    seq = env.make_step_sequence([hold.data_ptr()] * K, [out.data_ptr()] * K, packed=True)
+
+    hold_np = hold.cpu().numpy().astype(np.float64)
+
+    def active_fraction():
+        """share of the envs with a ray that hits within range, from the clamped ray distances of one more step on the
+        full-output path (a cell of the observation is the block MAX of 2 x 2 rays, sensor.py:131-137: it reads < 1 only
+        when all four hit -- reported beside it)"""
+        _, _, _, _ = env.step(hold_np, extras=True)
+        hit = float((env.intersec_dist < env.radar.max_dist).any(axis=1).mean())
+        cells = float((out[:, 16:n_obs] < 1.0).any(dim=1).float().mean().item())
+        return hit, cells
+
+    place_ray_dense(env, rng)
+    env.run_step_sequence(seq, stream=stream)
+    torch.cuda.synchronize()
+    times, act_end = [], []
+    while sum(times) < args.min_seconds / 4 and len(times) < args.max_reps:
+        place_ray_dense(env, rng)
+        env.step_device(hold.data_ptr(), out.data_ptr(), stream=stream, packed=True)
+        torch.cuda.synchronize()
+        act0 = active_fraction()[0]
+        t0 = time.perf_counter()
+        env.run_step_sequence(seq, stream=stream)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        act_end.append(active_fraction()[0])
+    med = statistics.median(times)
+    place_ray_dense(env, rng)
+    kernel_us, n_k = 0.0, 200
+    for i in range(n_k):
+        kernel_us += env.time_steps_device(hold.data_ptr(), out.data_ptr(), steps=1, stream=stream, packed=True)
+    kernel_us /= n_k
+    torch.cuda.synchronize()
+    res = {"workload": wl["name"] + " -- ray-dense operating point", "envs": N, "value": N * K / med, "unit": "env-steps/s",
+           "ms_per_step": med / K * 1e3, "reps": len(times), "steps_per_region": K, "kernel_us": kernel_us,
+           "active_fraction": {"what": "share of the envs with at least one ray that hits within range (clamped distance < max_dist)",
+                               "region_start": act0, "region_end_min": min(act_end), "after_kernel_timing": active_fraction()[0],
+                               "envs_with_a_cell_below_1": active_fraction()[1]},
+           "roofline": roofline_of(config_id, N, kernel_us, n_k, ksha, dense=True), "obs_finite": bool(torch.isfinite(out).all().item())}
+    env.close()
+    return res
+
+
+def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, kernel_launches=512, layout=""):
     """One workload on this GPU alone (no collective): open-loop regions, kernel duration by events, closed loop."""
-    wl = workload(config_id, envs)
+    wl = workload(config_id, envs, layout)
     N = wl["envs"]
     env = make_env(wl, local_rank, rank, args.threads)
     n_obs, n_u = env.n_observations, env.n_u
@@ -631,6 +746,17 @@ def main():
                                  "roofline": out["roofline"], "closed_loop": closed, "headline": True})
                 else:
                     subs.append(measure_single(cid, 0, args, torch, dev, local_rank, rank, ksha))
+                if cid == 5:     # both layouts of the mixed batch
+                    subs[-1]["layout"] = "interleaved"
+                    subs.append(measure_single(5, 0, args, torch, dev, local_rank, rank, ksha, layout="vehicle_sorted"))
+                    subs[-1]["layout"] = "vehicle_sorted"
+            for cid in (3, 4):   # the ray stage where a docking policy lives
+                subs.append(measure_ray_dense(cid, args, torch, dev, local_rank, rank, ksha))
+            if not args.no_cpu:  # the CPU path on the SAME scenario / vehicle / fan / step size, per config (a few seconds each)
+                for sub in subs:
+                    cid = int(sub["workload"][6])
+                    if cid != config_id and "ray-dense" not in sub["workload"] and sub.get("layout") != "vehicle_sorted":
+                        sub["cpu_baseline"] = cpu_baseline(workload(cid, 2), max(2.0, args.cpu_seconds / 4))
             out["configs"] = subs
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(wl, args.cpu_seconds)

@@ -18,14 +18,23 @@ ap.add_argument("--config", type=int, default=2)
 ap.add_argument("--envs", type=int, default=0)
 ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--shift", type=int, default=0, help="DOCKAUV_STAMP_SHIFT the library was built with")
+ap.add_argument("--dense", action="store_true", help="ray-dense operating point (bench.py: place_ray_dense), no reset, holding inputs")
 args = ap.parse_args()
 wl = bench.workload(args.config, args.envs)
 N = wl["envs"]
-env = BatchedDocking3d(wl["cfg"], num_envs=N, scenario=wl["scenario"], device=0, precision="f32", reset_mode="device",
+env = BatchedDocking3d(wl["cfg"], num_envs=N, scenario=wl["scenario"], device=0, precision="f32",
+                       reset_mode="none" if args.dense else "device",
                        device_seed=1, rng="batched", vehicles=wl["vehicles"], threads_per_group=args.threads)
+env._gen = np.random.default_rng(5)
 env.reset()
 dev = torch.device("cuda", 0)
 a = torch.rand((8, N, env.n_u), device=dev) * 2 - 1
+if args.dense:
+    bench.place_ray_dense(env, np.random.default_rng(6))
+    a.zero_()
+    if wl["cfg"]["vehicle"] == "BlueROV2":
+        a[:, :, 2] = 1.985 / 80.0
+    wl["name"] += " -- ray-dense"
 out = torch.zeros((N, env.n_observations + 2), device=dev)
 stream = torch.cuda.current_stream().cuda_stream
 lib = _capi.load_library()

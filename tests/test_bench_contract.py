@@ -47,7 +47,9 @@ def test_algorithmic_bytes_follow_the_survey_formula():
 
 def test_roofline_entry_shape():
     r = bench.roofline_of(3, 65536, 10.0, 100, "deadbeef0000")
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["limited_by"] == "latency"
+    assert bench.roofline_of(2, 4096, 4.5, 10, "x")["limited_by"] == "launch"
+    assert bench.roofline_of(4, 32768, 20.0, 10, "x", dense=True)["limited_by"] == "valu"
     assert np.isclose(r["achieved"], 420 * 65536 / 10e-6 / 1e9) and np.isclose(r["frac"], r["achieved"] / 8000.0)
     assert "traffic" in r
     if r["traffic"] is not None:   # committed counters: they must say where they come from, and that this is another kernel
@@ -90,8 +92,18 @@ def test_default_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and "SphereDocking3d" in c["sample"]
-    subs = {s["workload"][:7]: s for s in d["configs"]}
+    dense = [s for s in d["configs"] if "ray-dense" in s["workload"]]
+    assert sorted(s["workload"][:7] for s in dense) == ["config3", "config4"]
+    for s in dense:   # the ray stage where it is busy: >= 90 % of the fans have a hit, before and after the timed region
+        a = s["active_fraction"]
+        assert min(a["region_start"], a["region_end_min"], a["after_kernel_timing"]) >= 0.9, a
+        assert s["kernel_us"] > 0 and s["obs_finite"]
+    assert sorted(s.get("layout") for s in d["configs"] if s["workload"].startswith("config5")) == ["interleaved", "vehicle_sorted"]
+    subs = {s["workload"][:7]: s for s in d["configs"] if "ray-dense" not in s["workload"] and s.get("layout") != "vehicle_sorted"}
     assert set(subs) == {"config2", "config3", "config4", "config5"}
+    for k in ("config2", "config4", "config5"):   # the CPU path on the same scenario, per config
+        assert subs[k]["cpu_baseline"]["kind"] == "port" and subs[k]["cpu_baseline"]["value"] > 0
+    assert subs["config2"]["roofline"]["limited_by"] == "launch" and subs["config3"]["roofline"]["limited_by"] == "latency"
     for s in subs.values():
         assert s["kernel_us"] > 0 and 0 < s["roofline"]["frac"] < 1 and "traffic" in s["roofline"]
     assert subs["config2"]["envs"] == 4096 and subs["config4"]["envs"] == 32768 and subs["config5"]["envs"] == 65536
