@@ -158,7 +158,7 @@ def test_torch_env_matches_host_path():
     import torch
     from gym_dockauv_amd.envs.batched import BatchedDocking3d
     from gym_dockauv_amd.envs.torch_env import TorchDocking3d
-    N, K = 300, 25
+    N, K = 300, 40
     tenv = TorchDocking3d(num_envs=N, scenario="CapsuleCurrentDocking3d", device_seed=11)
     henv = BatchedDocking3d(num_envs=N, scenario="CapsuleCurrentDocking3d", precision="f32", reset_mode="device",
                             device_seed=11, rng="batched")
@@ -173,14 +173,22 @@ def test_torch_env_matches_host_path():
         n_done = 0
         for k in range(K):
             a = torch.rand((N, tenv.n_u), device=tenv.device, generator=g) * 2 - 1
-            obs, rew, done = tenv.step(a, want_terminal_obs=True)
+            # even steps ask for terminal observations (product kernel with the terminal copy, TERM), odd steps do not (plain
+            # product kernel); the host path runs the full instantiation: separate instantiations of one source contract a
+            # few multiply-adds differently, hence 5e-6 instead of bit equality over the free-running steps
+            want = k % 2 == 0
+            obs, rew, done = tenv.step(a, want_terminal_obs=want)
             ho, hr, hd, infos = henv.step(a.cpu().numpy())
-            assert np.array_equal(obs.cpu().numpy(), ho)
-            assert np.array_equal(rew.cpu().numpy(), hr)
+            np.testing.assert_allclose(obs.cpu().numpy(), ho, rtol=0, atol=5e-6)
+            np.testing.assert_allclose(rew.cpu().numpy(), hr, rtol=1e-5, atol=1e-5)
             assert np.array_equal(done.cpu().numpy(), hd)
-            for i in np.flatnonzero(hd):
-                assert np.array_equal(tenv.terminal_observation[i].cpu().numpy(), infos[i]["terminal_observation"])
-            n_done += int(hd.sum())
+            assert not bool(obs[done].any()), "rows of finished envs must hold the reset observation (zeros)"
+            if want:
+                for i in np.flatnonzero(hd):
+                    term = tenv.terminal_observation[i].cpu().numpy()
+                    np.testing.assert_allclose(term, infos[i]["terminal_observation"], rtol=0, atol=5e-6)
+                    assert np.abs(term).max() > 0
+                n_done += int(hd.sum())
         assert n_done > 0, "the run must cover auto-resets"
     finally:
         tenv.close()
@@ -287,5 +295,48 @@ def test_device_noise_matches_philox_reference(precision):
             got = env.get_field(_capi.F_CURRENT)[:, 0]
             np.testing.assert_allclose(got, vc, atol=1e-12 if precision == "f64" else 2e-6)
         assert np.ptp(vc[sigma > 0.05]) > 0.01 and np.all(np.abs(vc[::7] - vc[0]) < 1e-9)
+    finally:
+        env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["traj_ObstaclesCurrentDocking3d_bluerov2_random", "traj_SphereDocking3d_bluerov2_fan16_random",
+                                  "traj_ObstaclesDocking3d_lauv_near", "traj_SimpleDocking3d_bluerov2_roll"])
+def test_product_kernel_terminal_observation_vs_reference(name):
+    """The product kernel with the terminal copy (TERM: packed rows + terminal_obs on device pointers, in-kernel auto-reset)
+    against the reference: every env starts where a golden step started; where the reference's episode ends in that step
+    the packed row must be the reset observation (zeros, Q8) and terminal_obs the reference's last observation of the
+    episode (what SB3's DummyVecEnv hands to train.py:64-71 as infos[i]["terminal_observation"]); everywhere else the
+    packed row is the reference's observation and terminal_obs is left untouched."""
+    import torch
+    from tests import helpers as H
+    g = H.load(name)
+    T = int(g["meta_T"])
+    env, max_caps, max_sph = H.make_batched(g, T, "f32", reset_mode="device", device_seed=3, rng="batched")
+    try:
+        inp = H.teacher_forced_inputs(g, np.arange(T), max_caps, max_sph)
+        H.load_teacher_forced(env, inp)
+        dev = torch.device("cuda", env.device)
+        n = env.n_observations
+        out = torch.zeros((T, n + 2), device=dev)
+        term = torch.full((T, n), -7.0, device=dev)
+        a = torch.as_tensor(inp["actions"][:, :env.n_u], dtype=torch.float32, device=dev).contiguous()
+        env.step_device(a.data_ptr(), out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, packed=True,
+                        terminal_obs_ptr=term.data_ptr())
+        torch.cuda.synchronize()
+        o, t_ = out.cpu().numpy(), term.cpu().numpy()
+        gold = inp["gold"]
+        dn = gold["done"].astype(bool)
+        assert dn.sum() >= 1, "the trajectory must contain terminal steps"
+        assert np.array_equal(o[:, n + 1] > 0.5, dn)
+        assert not o[dn, :n].any(), "finished envs: reset observation"
+        assert np.all(t_[~dn] == -7.0), "terminal_obs is written only where done"
+        d = np.abs(t_[dn] - gold["obs"][dn])
+        d[:, 2] = np.minimum(d[:, 2], np.abs(2.0 - d[:, 2]))
+        assert d[:, :16].max() <= 1e-5 and d[:, 16:].max(initial=0.0) <= 5e-5, d.max()
+        d2 = np.abs(o[~dn, :n] - gold["obs"][~dn])
+        d2[:, 2] = np.minimum(d2[:, 2], np.abs(2.0 - d2[:, 2]))
+        assert d2[:, :16].max() <= 1e-5
+        np.testing.assert_allclose(o[:, n], gold["reward"], rtol=2e-5, atol=2e-5)
     finally:
         env.close()
