@@ -444,6 +444,10 @@ def main():
                          "as BASELINE's north_star names it; auto = peer-to-peer push (dockauv_p2p_*) if it maps and "
                          "reproduces the RCCL all-gather bit for bit during warm-up, else RCCL (the links bound the step "
                          "either way, DESIGN.md section 7; the push has only run with ranks sharing one GPU)")
+    ap.add_argument("--gather-dtype", choices=["f32", "bf16"], default="f32",
+                    help="N > 1: what crosses xGMI per env and step.  f32 (default): the packed float32 rows, bit for bit; "
+                         "bf16: observation columns as bfloat16 (half the bytes; reward / done stay float32).  The f32 line "
+                         "also carries a `bf16_gather` sub-measurement of the same regions")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--sweep", type=int, nargs="*", default=[262144, 1048576])
     args = ap.parse_args()
@@ -499,11 +503,16 @@ def main():
     # of the gather buffer; ONE gather per step, overlapped with the next step's kernel (two buffers)
     from gym_dockauv_amd.parallel import ShardedStepper
 
-    def step_fn(a, out_local):
-        env.step_device(a.data_ptr(), out_local.data_ptr(), stream=stream, packed=True)
+    pack_mode = "bf16" if (args.gather_dtype == "bf16" and use_dist) else True
 
-    stepper = ShardedStepper(N, n_obs + 2, step_fn, dev, world=world, rank=rank, overlap=not args.no_overlap)
+    def step_fn(a, out_local):
+        env.step_device(a.data_ptr(), out_local.data_ptr(), stream=stream, packed=pack_mode)
+
+    stepper = ShardedStepper(N, env.packed_row_words(pack_mode), step_fn, dev, world=world, rank=rank, overlap=not args.no_overlap,
+                             gather_dtype="bf16" if pack_mode == "bf16" else "f32")
     stepper.use_dist = use_dist
+    if pack_mode == "bf16" and args.gather != "rccl":
+        raise SystemExit("--gather-dtype bf16 is implemented for the RCCL transport")
     rccl_stepper = stepper
     transport, p2p_note, n_verify = ("rccl" if use_dist else "none"), None, 0
     if use_dist and args.gather in ("auto", "p2p"):
@@ -630,7 +639,7 @@ def main():
             key = (n, i0 % RING)
             if key not in alone_cache:
                 alone_cache[key] = env.make_step_sequence([actions[i % RING].data_ptr() for i in range(i0, i0 + n)],
-                                                          [out_l.data_ptr()] * n, packed=True)
+                                                          [out_l.data_ptr()] * n, packed=pack_mode)
             env.run_step_sequence(alone_cache[key], stream=stream)
 
         t_alone = timed_regions(run_alone, args.steps, min(args.warmup, 50), 0, args.min_seconds / 2, args.max_reps,
@@ -640,17 +649,44 @@ def main():
                  "reps": len(t_alone), "what": "the same shard on every rank at once, no gather (max over ranks)",
                  "weak_scaling_efficiency_of_this_line": (world * N * args.steps / dt) / (world * N * args.steps / d_alone)}
 
+    # the same regions with half-precision rows over the links (RCCL transport): observation columns bfloat16
+    bf16_gather = None
+    if use_dist and transport == "rccl" and pack_mode is True and os.environ.get("DOCKAUV_DIST_BACKEND", "nccl") != "gloo":
+        def step_fn16(a, out_local):
+            env.step_device(a.data_ptr(), out_local.data_ptr(), stream=stream, packed="bf16")
+        st16 = ShardedStepper(N, env.packed_row_words("bf16"), step_fn16, dev, world=world, rank=rank, overlap=not args.no_overlap,
+                              gather_dtype="bf16")
+        st16.use_dist = True
+
+        def run16(n, i0=0):
+            for i in range(i0, i0 + n):
+                st16.step(actions[i % RING])
+            st16.wait()
+        t16 = timed_regions(run16, args.steps, min(args.warmup, 100), 0, args.min_seconds / 2, args.max_reps,
+                            torch.cuda.synchronize, barrier, reduce_max)
+        d16 = statistics.median(t16)
+        bf16_gather = {"value": world * N * args.steps / d16, "unit": "env-steps/s", "ms_per_step": d16 / args.steps * 1e3,
+                       "reps": len(t16), "bytes_per_rank_per_step": st16.bytes_per_rank_per_step,
+                       "what": "the same steps with observation columns gathered as bfloat16 (round to nearest even; reward / "
+                               "done float32): include/dockauv.h pack_reward_done = 2"}
+        del st16
+
     # roofline of the dominant (only) kernel: per-dispatch start/stop events on the launch stream, cycling through
     # the same action ring as the timed region
     n_timed = min(max(args.steps, 256), 1024)
     kernel_us = 0.0
     for i in range(n_timed):
-        kernel_us += env.time_steps_device(actions[i % RING].data_ptr(), out_l.data_ptr(), steps=1, stream=stream, packed=True)
+        kernel_us += env.time_steps_device(actions[i % RING].data_ptr(), out_l.data_ptr(), steps=1, stream=stream, packed=pack_mode)
     kernel_us /= n_timed
     torch.cuda.synchronize()
     last = stepper.bufs[0]
-    finite = bool(torch.isfinite(last).all().item())
-    n_done = int((out_l[:, n_obs + 1] > 0.5).sum().item())
+    if pack_mode == "bf16":
+        o16, r16, d16_ = ShardedStepper.split_bf16(last, n_obs)
+        finite = bool(torch.isfinite(o16.float()).all().item() and torch.isfinite(r16).all().item())
+        n_done = int(ShardedStepper.split_bf16(out_l, n_obs)[2].sum().item())
+    else:
+        finite = bool(torch.isfinite(last).all().item())
+        n_done = int((out_l[:, n_obs + 1] > 0.5).sum().item())
     closed = closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400) if world == 1 and not use_dist else None
 
     sweep = []
@@ -724,6 +760,9 @@ def main():
                        "timing": f"median of {len(times)} regions of {args.steps} steps (>= {args.min_seconds} s measured in all), "
                                  "each between barrier + synchronize, max over ranks; open loop: actions from a ring resident in HBM",
                        "collective": collective,
+                       "gather_dtype": ("bf16" if pack_mode == "bf16" else "f32") if use_dist else None,
+                       "gather_bytes_per_rank_per_step": (stepper.bytes_per_rank_per_step if hasattr(stepper, "bytes_per_rank_per_step")
+                                                          else N * (n_obs + 2) * 4) if use_dist else 0,
                        "world_size": (dist.get_world_size() if use_dist else 1), "backend": backend, "ranks": devices,
                        **({"gather_note": p2p_note} if p2p_note else {}),
                        **({"rccl_all_gather_ms_per_step_python_issued": rccl_ms} if rccl_ms is not None else {}),
@@ -735,6 +774,8 @@ def main():
             out["closed_loop"] = closed
         if alone:
             out["same_workload_without_gather"] = alone
+        if bf16_gather:
+            out["bf16_gather"] = bf16_gather
         if sweep:
             out["sweep"] = sweep
         if world == 1 and not use_dist and not args.no_configs and not args.envs:

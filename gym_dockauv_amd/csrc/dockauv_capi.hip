@@ -175,6 +175,8 @@ void fill_env(EnvP<T>& e, const dockauv_env_s& h) {
     e.max_cap = c.max_capsules;
     e.max_sph = c.max_spheres;
     e.n_u_max = h.n_u_max;
+    e.bf16_wpr = (h.n_obs + 1) / 2 + 2;
+    e.bf16_magic = (unsigned)((0x100000000ull / (unsigned)e.bf16_wpr) + 1ull);   // floor(idx / wpr) = mul_hi(idx, magic), idx < 2^16
     e.seed = c.seed;
     e.h = (T)c.t_step_size;
     e.lp_alpha = (T)(c.t_step_size / (c.t_step_size + c.lowpass_T1));   // utils/lowpassfilter.py:27
@@ -293,7 +295,7 @@ void set_io(StepIO& d, const dockauv_step_io& s) {
     d.ray_dist = s.ray_dist;
     d.terminal_obs = s.terminal_obs;
     d.state_dot = s.state_dot;
-    d.pack = s.pack_reward_done ? 1 : 0;
+    d.pack = s.pack_reward_done == 2 ? 2 : (s.pack_reward_done ? 1 : 0);
 }
 
 int launch(dockauv_handle h, const dockauv_step_io* io, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {

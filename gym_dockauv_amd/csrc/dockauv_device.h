@@ -58,6 +58,10 @@ struct EnvP {
     // ray stage with one lane per ray (fans of <= 64 rays): lanes per env (power of two >= n_rays), the circular cone
     // that contains the fan (cos / sin of its half-angle, widened by 1e-3 rad), the sum of the obstacle-avoidance
     // weights over all rays
+    // packed rows with bfloat16 observation columns (dockauv_step_io::pack_reward_done == 2): 32-bit words per row
+    // (ceil(n_obs / 2) pairs + reward + done) and the multiplier that divides a word index by it (mul_hi)
+    int bf16_wpr;
+    unsigned bf16_magic;
     int ray_pad, ray_pad_log2;
     int device_noise;    // 1: the kernel draws the current's white noise itself (dockauv_config::device_noise)
     T fan_cos, fan_sin, sum_beta;
@@ -113,7 +117,7 @@ struct StepIO {
     void* state_dot;          // T [N][12] or null
     const void* trace;        // TraceDev in device memory or null (library-owned, dockauv_trace_enable)
     long long trace_step;     // index of this step in the trace
-    int pack;
+    int pack;                 // 0: separate reward / done; 1: packed float32 rows; 2: packed rows, observation columns bfloat16
     int device_noise;         // 1: no noise array given and the handle draws the current's white noise itself
 };
 

@@ -506,14 +506,27 @@ class BatchedDocking3d:
         return self.episode_storage
 
     # ------------------------------------------------------------------------------------------ device-pointer path
+    @staticmethod
+    def _pack_mode(packed) -> int:
+        """packed: False / True (float32 rows [obs | reward | done]) / "bf16" (observation columns bfloat16, two per word;
+        include/dockauv.h: pack_reward_done = 2)"""
+        if packed in ("bf16", 2):
+            return 2
+        return 1 if packed else 0
+
+    def packed_row_words(self, packed=True) -> int:
+        """32-bit words per packed row: n_obs + 2 (float32 rows) or ceil(n_obs / 2) + 2 ("bf16")"""
+        return (self.n_observations + 1) // 2 + 2 if self._pack_mode(packed) == 2 else self.n_observations + 2
+
     def step_device(self, actions_ptr: int, obs_ptr: int, reward_ptr: int = 0, done_ptr: int = 0, stream: int = 0,
                     noise_ptr: int = 0, terminal_obs_ptr: int = 0, conditions_ptr: int = 0, packed: bool = False) -> None:
         """Asynchronous step on device pointers (torch tensors' data_ptr()): no host copies, no sync.
-        packed=True: obs_ptr is a float32 [N][n_obs + 2] buffer receiving obs | reward | done per env."""
+        packed=True: obs_ptr is a float32 [N][n_obs + 2] buffer receiving obs | reward | done per env; packed="bf16": a
+        uint32 [N][ceil(n_obs / 2) + 2] buffer, observation columns as bfloat16 pairs (packed_row_words)."""
         io = _capi.StepIO()
         io.actions, io.obs = actions_ptr, obs_ptr
         io.reward, io.done = reward_ptr or None, done_ptr or None
-        io.pack_reward_done = 1 if packed else 0
+        io.pack_reward_done = self._pack_mode(packed)
         io.noise = noise_ptr or None
         io.terminal_obs = terminal_obs_ptr or None
         io.conditions = conditions_ptr or None
@@ -531,7 +544,7 @@ class BatchedDocking3d:
         ios = (_capi.StepIO * n)()
         for i in range(n):
             ios[i].actions, ios[i].obs = actions_ptrs[i], obs_ptrs[i]
-            ios[i].pack_reward_done = 1
+            ios[i].pack_reward_done = self._pack_mode(packed)
         return ios
 
     def run_step_sequence(self, ios, stream: int = 0) -> None:
@@ -545,7 +558,7 @@ class BatchedDocking3d:
         io = _capi.StepIO()
         io.actions, io.obs = actions_ptr, obs_ptr
         io.reward, io.done = reward_ptr or None, done_ptr or None
-        io.pack_reward_done = 1 if packed else 0
+        io.pack_reward_done = self._pack_mode(packed)
         out = C.c_double(0.0)
         rc = self._lib.dockauv_time_steps(self._handle, C.byref(io), C.c_void_p(stream or None), int(steps), C.byref(out))
         _capi.check(self._lib, self._handle, rc, "dockauv_time_steps")

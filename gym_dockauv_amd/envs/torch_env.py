@@ -97,14 +97,18 @@ class ShardedTorchDocking3d:
 
     def __init__(self, env_config: dict = BASE_CONFIG, num_envs: int = 4096, scenario: str = "SimpleDocking3d",
                  device: int = 0, transport: str = "rccl", group=None, device_seed: int = 0, host_seed: Optional[int] = None,
-                 vehicles=None, verify_steps: int = 4, check_every: int = 64, p2p_max_spins: int = 8_000_000, **kw):
+                 vehicles=None, verify_steps: int = 4, check_every: int = 64, p2p_max_spins: int = 8_000_000,
+                 gather_dtype: str = "f32", **kw):
         """transport: "rccl" (default: one all_gather_into_tensor per step, what BASELINE.json names) or "p2p" (the
         peer-to-peer push of gym_dockauv_amd/parallel.py).  p2p is only kept if, on EVERY rank, `verify_steps` gathers of
         test rows equal an RCCL all-gather of the same rows bit for bit; otherwise the env falls back to RCCL
         (``self.transport`` says which one runs, ``self.transport_note`` why).  With p2p the time-out word of the
         transport is read every `check_every` steps and in close(): a peer whose step stamp did not arrive within the
         spin bound makes step() raise DockAUVError on every rank that waited for it (the rows it would have returned
-        are stale) -- the job is then to be restarted as fresh processes."""
+        are stale) -- the job is then to be restarted as fresh processes.
+        gather_dtype: "f32" (default: the gathered observations are the kernel's, bit for bit) or "bf16" (RCCL transport:
+        the kernel writes the observation columns as bfloat16, round to nearest even, and the links carry half the
+        bytes; step() then returns a bfloat16 observation view; reward / done stay float32)."""
         import numpy as np
         import torch
         import torch.distributed as dist
@@ -133,17 +137,24 @@ class ShardedTorchDocking3d:
         self.n_obs, self.n_u = self.batch.n_observations, self.batch.n_u
         self.observation_space, self.action_space = self.batch.observation_space, self.batch.action_space
         self.transport, self.transport_note = transport, None
+        if gather_dtype not in ("f32", "bf16"):
+            raise ValueError("gather_dtype must be 'f32' or 'bf16'")
+        if gather_dtype == "bf16" and transport != "rccl":
+            raise ValueError("gather_dtype='bf16' is implemented for the RCCL transport")
+        self.gather_dtype = gather_dtype
+        packed = "bf16" if gather_dtype == "bf16" else True
+        row_words = self.batch.packed_row_words(packed)
         self.check_every = max(1, int(check_every))
         self._steps = 0
         self._DockAUVError = DockAUVError
 
         def step_fn(actions_local, out_local):
             self.batch.step_device(actions_local.data_ptr(), out_local.data_ptr(),
-                                   stream=torch.cuda.current_stream().cuda_stream, packed=True)
+                                   stream=torch.cuda.current_stream().cuda_stream, packed=packed)
 
         def rccl_stepper():
-            return ShardedStepper(self.n_local, self.n_obs + 2, step_fn, self.device, world=self.world,
-                                  rank=self.rank, group=group, overlap=False)
+            return ShardedStepper(self.n_local, row_words, step_fn, self.device, world=self.world,
+                                  rank=self.rank, group=group, overlap=False, gather_dtype=gather_dtype)
 
         if transport == "p2p":
             p2p, note = None, None
@@ -214,6 +225,9 @@ class ShardedTorchDocking3d:
         self._steps += 1
         if self._steps % self.check_every == 0:
             self._check_transport()
+        if self.gather_dtype == "bf16":
+            from ..parallel import ShardedStepper
+            return ShardedStepper.split_bf16(buf, self.n_obs)
         return buf[:, : self.n_obs], buf[:, self.n_obs], buf[:, self.n_obs + 1] > 0.5
 
     def close(self) -> None:

@@ -35,15 +35,24 @@ class ShardedStepper:
     """
 
     def __init__(self, n_local: int, row_len: int, step_fn: Callable, device, world: int = 1, rank: int = 0,
-                 group=None, overlap: bool = True, n_buffers: int = 2):
+                 group=None, overlap: bool = True, n_buffers: int = 2, gather_dtype: str = "f32"):
+        """gather_dtype "bf16": the rows the kernel writes (and the links carry) hold the observation columns as bfloat16
+        pairs -- `row_len` is then the row length in 32-bit words, ceil(n_obs / 2) + 2 (BatchedDocking3d.packed_row_words,
+        step_fn launches with packed="bf16"); reward and done stay float32.  Halves the bytes over xGMI; the learner gets
+        observations rounded to nearest even bfloat16 (what a bf16 policy network would make of them anyway)."""
         import torch
         self.torch = torch
         self.n_local, self.row_len, self.world, self.rank = int(n_local), int(row_len), int(world), int(rank)
+        if gather_dtype not in ("f32", "bf16"):
+            raise ValueError("gather_dtype must be 'f32' or 'bf16'")
+        self.gather_dtype = gather_dtype
         self.step_fn = step_fn
         self.group = group
         self.overlap = bool(overlap) and world > 1
+        # (bf16 rows are addressed as 32-bit words: float32 storage, reinterpreted by split_bf16)
         self.bufs = [torch.zeros((world * n_local, row_len), device=device, dtype=torch.float32)
                      for _ in range(n_buffers if self.overlap else 1)]
+        self.bytes_per_rank_per_step = self.n_local * self.row_len * 4
         self.works: List[Optional[object]] = [None] * len(self.bufs)
         self.i = 0
         self.use_dist = world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())
@@ -78,6 +87,14 @@ class ShardedStepper:
     def split(buf, n_obs: int):
         """Views into a gathered buffer: obs [N, n_obs], reward [N], done [N] (bool)."""
         return buf[:, :n_obs], buf[:, n_obs], buf[:, n_obs + 1] > 0.5
+
+    @staticmethod
+    def split_bf16(buf, n_obs: int):
+        """The same for gather_dtype "bf16": obs [N, n_obs] as a bfloat16 view (no copy), reward [N] float32, done [N]."""
+        import torch
+        npair = (n_obs + 1) // 2
+        obs = buf[:, :npair].view(torch.bfloat16)[:, :n_obs]
+        return obs, buf[:, npair], buf[:, npair + 1] > 0.5
 
 
 class _DevArray:

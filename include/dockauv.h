@@ -164,9 +164,12 @@ typedef struct dockauv_env_s* dockauv_handle;
 typedef struct dockauv_step_io {
     const void* actions;     /* T [n_envs][n_u_max] row-major, raw policy output (clipped inside, auvsim.py:74) */
     const void* noise;       /* nullable, T [n_envs]: w_k ~ N(0, sigma) of Current.sim (current.py:88); NULL = 0 */
-    float* obs;              /* float32 [n_envs][n_obs] row-major (docking3d.py:462-488); with pack_reward_done:
+    float* obs;              /* float32 [n_envs][n_obs] row-major (docking3d.py:462-488); with pack_reward_done = 1:
                                 float32 [n_envs][n_obs + 2] = obs | reward | done(0.0/1.0), one dense buffer so that a
-                                single all-gather ships everything a learner needs */
+                                single all-gather ships everything a learner needs; with pack_reward_done = 2 the
+                                observation columns are bfloat16 (round to nearest even), two per 32-bit word:
+                                uint32 [n_envs][ceil(n_obs / 2) + 2] = obs pairs (low half first; an odd n_obs is padded
+                                with 0) | reward (float32) | done (float32) -- half the bytes over xGMI */
     void* reward;            /* T [n_envs] (docking3d.py:593); nullable when pack_reward_done */
     uint8_t* done;           /* [n_envs] 0/1 (docking3d.py:630); nullable when pack_reward_done */
     void* reward_terms;      /* nullable, T [n_envs][13]: last_reward_arr (docking3d.py:513-588) */
@@ -177,7 +180,7 @@ typedef struct dockauv_step_io {
     void* state_dot;         /* nullable, T [n_envs][12]: AUVSim._state_dot, the right-hand side at the new state with the
                                 new input (objects/auvsim.py:108), what EpisodeDataStorage logs as "states_dot"
                                 (utils/datastorage.py:272,299) */
-    int32_t pack_reward_done; /* 0/1, see obs */
+    int32_t pack_reward_done; /* 0 / 1 / 2, see obs */
     int32_t reserved;
 } dockauv_step_io;
 

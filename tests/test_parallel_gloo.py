@@ -93,3 +93,65 @@ def test_two_rank_gather_equals_single_process(overlap):
     import torch
     obs, rew, done = ShardedStepper.split(torch.from_numpy(got[0][0]), n_obs)
     assert obs.shape == (total, n_obs) and rew.shape == (total,) and done.dtype == torch.bool and done.sum() == total // 2
+
+
+def _worker_bf16(rank, world, port, n_local, n_obs, q):
+    """gather_dtype "bf16": rows of ceil(n_obs / 2) + 2 words; the stand-in env packs bfloat16 pairs the way the kernel does"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from gym_dockauv_amd.parallel import ShardedStepper, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        first, count = shard_range(world * n_local, world, rank)
+        npair = (n_obs + 1) // 2
+        wpr = npair + 2
+
+        def step_fn(actions_local, out_local):
+            obs = (torch.arange(first, first + count, dtype=torch.float32)[:, None] * 0.37 + torch.arange(n_obs)[None, :] * 1.001)
+            pad = torch.zeros((count, 2 * npair), dtype=torch.bfloat16)
+            pad[:, :n_obs] = obs.to(torch.bfloat16)                         # round to nearest even
+            out_local[:, :npair] = pad.view(torch.float32)
+            out_local[:, npair] = actions_local.sum(dim=1)
+            out_local[:, npair + 1] = (torch.arange(first, first + count) % 3 == 0).float()
+
+        st = ShardedStepper(n_local, wpr, step_fn, "cpu", world=world, rank=rank, overlap=False, gather_dtype="bf16")
+        assert st.bytes_per_rank_per_step == n_local * wpr * 4
+        buf = st.step(torch.ones((count, 3)) * (rank + 1))
+        st.wait()
+        obs, rew, done = ShardedStepper.split_bf16(buf, n_obs)
+        q.put((rank, obs.float().numpy(), rew.numpy(), done.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_obs", [20, 7])
+def test_two_rank_bf16_gather(n_obs):
+    import torch
+    import torch.multiprocessing as mp
+    world, n_local = 2, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + (os.getpid() % 100) + n_obs
+    procs = [ctx.Process(target=_worker_bf16, args=(r, world, port, n_local, n_obs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, obs, rew, done = q.get(timeout=120)
+        got[r] = (obs, rew, done)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total = world * n_local
+    exp = (torch.arange(total, dtype=torch.float32)[:, None] * 0.37 + torch.arange(n_obs)[None, :] * 1.001).to(torch.bfloat16).float().numpy()
+    for r in range(world):
+        obs, rew, done = got[r]
+        np.testing.assert_array_equal(obs, exp)
+        np.testing.assert_array_equal(rew, np.repeat([3.0, 6.0], n_local))
+        np.testing.assert_array_equal(done, np.arange(total) % 3 == 0)
+    with pytest.raises(ValueError):
+        from gym_dockauv_amd.parallel import ShardedStepper
+        ShardedStepper(4, 8, lambda a, o: None, "cpu", gather_dtype="fp8")
