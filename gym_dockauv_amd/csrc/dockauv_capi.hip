@@ -301,8 +301,16 @@ void set_io(StepIO& d, const dockauv_step_io& s) {
 int launch(dockauv_handle h, const dockauv_step_io* io, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     int rc;
     StepIO& sio = h->f64 ? h->a64.io : h->a32.io;
+    if (h->trace_dev) {
+        // The ring row of a step is a kernel ARGUMENT (host counter): a launch captured into a HIP graph would write the
+        // same row on every replay and dockauv_trace_steps would never advance -- refused rather than silently dropped.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(h, DOCKAUV_E_INVALID, "the episode-storage trace (dockauv_trace_enable) cannot be recorded into a HIP graph: "
+                        "its ring row is a launch argument; disable the trace or launch the steps directly");
+    }
     sio.trace = h->trace_dev;
-    sio.trace_step = h->trace_dev ? h->trace_step++ : 0;
+    sio.trace_step = h->trace_dev ? h->trace_step : 0;
     sio.device_noise = (h->cfg.device_noise && !io->noise) ? 1 : 0;
     if (h->f64) {
         set_io(h->a64.io, *io);
@@ -312,6 +320,7 @@ int launch(dockauv_handle h, const dockauv_step_io* io, hipStream_t stream, hipE
         rc = launch_step_f32(h->a32, h->vk, h->sym, h->has_rays, h->threads, stream, ev0, ev1);
     }
     if (rc != 0) return fail(h, DOCKAUV_E_HIP, "step kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (h->trace_dev) ++h->trace_step;   // (only a launch that went out has written its row)
     h->last_stream = stream;
     return 0;
 }

@@ -346,6 +346,8 @@ class BatchedDocking3d:
         if seed is not None:
             self.seed(seed)
         idx = np.arange(self.num_envs)
+        if self.episode_storage is not None:
+            self.episode_storage.on_reset(idx)
         rc = self._lib.dockauv_reset_envs(self._handle, 0, self.num_envs)
         _capi.check(self._lib, self._handle, rc, "dockauv_reset_envs")
         self.load_episodes(idx, self.generate_episodes(idx, reseed=seed is not None or self._seeds is not None))
@@ -374,6 +376,8 @@ class BatchedDocking3d:
         idx = np.asarray(idx, dtype=np.int64)
         if idx.size == 0:
             return
+        if self.episode_storage is not None:
+            self.episode_storage.on_reset(idx)
         breaks = np.flatnonzero(np.diff(idx) != 1) + 1
         for run in np.split(idx, breaks):
             rc = self._lib.dockauv_reset_envs(self._handle, int(run[0]), int(run.size))

@@ -97,7 +97,7 @@ class ShardedTorchDocking3d:
 
     def __init__(self, env_config: dict = BASE_CONFIG, num_envs: int = 4096, scenario: str = "SimpleDocking3d",
                  device: int = 0, transport: str = "rccl", group=None, device_seed: int = 0, host_seed: Optional[int] = None,
-                 vehicles=None, verify_steps: int = 4, check_every: int = 64, p2p_max_spins: int = 8_000_000,
+                 vehicles=None, verify_steps: int = 4, check_every: int = 8, p2p_max_spins: int = 8_000_000,
                  gather_dtype: str = "f32", **kw):
         """transport: "rccl" (default: one all_gather_into_tensor per step, what BASELINE.json names) or "p2p" (the
         peer-to-peer push of gym_dockauv_amd/parallel.py).  p2p is only kept if, on EVERY rank, `verify_steps` gathers of
@@ -105,7 +105,9 @@ class ShardedTorchDocking3d:
         (``self.transport`` says which one runs, ``self.transport_note`` why).  With p2p the time-out word of the
         transport is read every `check_every` steps and in close(): a peer whose step stamp did not arrive within the
         spin bound makes step() raise DockAUVError on every rank that waited for it (the rows it would have returned
-        are stale) -- the job is then to be restarted as fresh processes.
+        are stale) -- the job is then to be restarted as fresh processes.  The rows of up to `check_every` - 1 steps
+        returned BEFORE the raise may already have been stale: a learner discards its last `check_every` steps on that
+        error (default 8: one 8-byte read-back every eighth step).
         gather_dtype: "f32" (default: the gathered observations are the kernel's, bit for bit) or "bf16" (RCCL transport:
         the kernel writes the observation columns as bfloat16, round to nearest even, and the links carry half the
         bytes; step() then returns a bfloat16 observation view; reward / done stay float32)."""

@@ -219,6 +219,7 @@ class BatchEpisodeStorage:
         self.ids = np.array(env._trace_ids)
         self._flushed = 0                                   # steps already looked at
         self._open = {int(i): [] for i in self.ids}         # env id -> list of per-step dicts of the running episode
+        self._closed = {int(i): False for i in self.ids}    # env id -> its episode has ended and was written (reset_mode "none")
         self._episode_no = {int(i): 1 for i in self.ids}
         self.files = []
         if len(path_folder) > 0:
@@ -242,9 +243,30 @@ class BatchEpisodeStorage:
         written = []
         for j, env_id in enumerate(self.ids.tolist()):
             for k in range(n_new):
+                if self._closed[env_id]:
+                    # reset_mode "none": a finished env that is stepped on reports its conditions on every step -- the
+                    # episode closed on the 0 -> non-zero edge; what follows belongs to no episode until the env is reset
+                    continue
                 self._open[env_id].append({key: tr[key][k, j] for key in tr})
                 if tr["conditions"][k, j] != 0:
                     written.append(self._save(env_id))
+                    if not self.env.auto_reset:
+                        self._closed[env_id] = True
+        return written
+
+    def on_reset(self, env_ids, save_partial: bool = False):
+        """Host-side reset of `env_ids` (BatchedDocking3d.reset / reset_envs): the steps recorded so far are pulled from
+        the ring first; a selected env's running (unfinished) episode is dropped -- or written with save_partial, as the
+        reference saves its storage inside reset() (envs/docking3d.py:252-256) -- so that its rows never join the next
+        episode's."""
+        written = self.flush()
+        for env_id in np.intersect1d(np.asarray(env_ids, dtype=np.int64), self.ids).tolist():
+            if self._open[env_id]:
+                if save_partial:
+                    written.append(self._save(env_id))
+                else:
+                    self._open[env_id] = []
+            self._closed[env_id] = False
         return written
 
     def _save(self, env_id: int) -> str:

@@ -126,3 +126,73 @@ def test_state_dot_output_matches_oracle(precision):
                 np.testing.assert_allclose(sd[i], sd_ref, rtol=1e-7 if precision == "f64" else 2e-3, atol=1e-8 if precision == "f64" else 2e-4)
         finally:
             env.close()
+
+
+def test_storage_across_host_resets_and_after_done(tmp_path):
+    """(a) a mid-episode host reset must not join the abandoned rows to the next episode; (b) with
+    reset_mode "none" a finished env that is stepped on reports its conditions every step -- ONE pickle, not one per step."""
+    name = "traj_ObstaclesCurrentDocking3d_bluerov2_random"
+    g = H.load(name)
+    n_u = int(g["meta_n_u"])
+    N, sel = 70, [5, 66]
+    env, max_caps, max_sph = H.make_batched(g, N, "f64", auto_reset=False)
+    try:
+        store = env.enable_episode_storage(sel, str(tmp_path), title="r", capacity=128)
+        env.reset()
+        env.reset_envs(sel, H.episode_arrays(g, [0] * len(sel), max_caps, max_sph))
+        a = np.zeros((N, env.n_u))
+        for t in range(10):                                   # ten steps of episode 0 ...
+            a[sel, :n_u] = g["action"][t]
+            env.step(a)
+        env.reset_envs(sel, H.episode_arrays(g, [1] * len(sel), max_caps, max_sph))   # ... abandoned by a host reset
+        assert store.files == []
+        first_done = None
+        for t in range(int(g["meta_max_timesteps"]) + 8):     # episode 1 to its time limit, then stepped on 7 more times
+            a[sel, :n_u] = g["action"][(int(g["ep_start"][1]) + t) % int(g["meta_T"])]
+            _, _, done, _ = env.step(a)
+            if first_done is None and done[sel[0]]:
+                first_done = t
+        store.flush()
+        assert first_done is not None
+        assert len(store.files) == len(sel), store.files      # one pickle per selected env
+        st = pickle.load(open(store.files[0], "rb"))
+        assert st["vehicle"]["states"].shape[0] == first_done + 2          # reset row + its own steps only
+        np.testing.assert_allclose(st["vehicle"]["states"][0, 0:3], g["ep_position"][1], atol=1e-9)
+        assert st["conditions_last_step"] != 0
+    finally:
+        env.close()
+
+
+def test_trace_refuses_hip_graph_capture():
+    """The ring row of a step is a launch argument: capturing a traced step into a HIP graph would write one row over and
+    over.  The library refuses (DOCKAUV_E_INVALID) instead of dropping steps silently; without a trace capture works."""
+    import torch
+    from gym_dockauv_amd._capi import DockAUVError
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    env = BatchedDocking3d(num_envs=256, scenario="SimpleDocking3d", precision="f32", reset_mode="device", rng="batched")
+    try:
+        env.reset()
+        dev = torch.device("cuda", 0)
+        a = torch.zeros((256, env.n_u), device=dev)
+        out = torch.zeros((256, env.n_observations + 2), device=dev)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            env.step_device(a.data_ptr(), out.data_ptr(), stream=s.cuda_stream, packed=True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                env.step_device(a.data_ptr(), out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, packed=True)
+            g.replay()
+        torch.cuda.synchronize()
+        env.enable_episode_storage([1, 2], "", title="g", capacity=16)
+        n0 = env.trace_steps()
+        g2 = torch.cuda.CUDAGraph()
+        with pytest.raises(DockAUVError, match="HIP graph"):
+            with torch.cuda.graph(g2, stream=s):
+                env.step_device(a.data_ptr(), out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, packed=True)
+        torch.cuda.synchronize()
+        assert env.trace_steps() == n0
+        env.step_device(a.data_ptr(), out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, packed=True)
+        torch.cuda.synchronize()
+        assert env.trace_steps() == n0 + 1
+    finally:
+        env.close()
