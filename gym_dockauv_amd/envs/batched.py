@@ -557,11 +557,12 @@ class BatchedDocking3d:
         _capi.check(self._lib, self._handle, rc, "dockauv_step_sequence")
 
     def time_steps_device(self, actions_ptr: int, obs_ptr: int, reward_ptr: int = 0, done_ptr: int = 0, steps: int = 1,
-                          stream: int = 0, packed: bool = False) -> float:
+                          stream: int = 0, packed: bool = False, terminal_obs_ptr: int = 0) -> float:
         """Average KERNEL duration in microseconds from per-dispatch HIP events on `stream` (bench.py)."""
         io = _capi.StepIO()
         io.actions, io.obs = actions_ptr, obs_ptr
         io.reward, io.done = reward_ptr or None, done_ptr or None
+        io.terminal_obs = terminal_obs_ptr or None
         io.pack_reward_done = self._pack_mode(packed)
         out = C.c_double(0.0)
         rc = self._lib.dockauv_time_steps(self._handle, C.byref(io), C.c_void_p(stream or None), int(steps), C.byref(out))
