@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=3)
 ap.add_argument("--envs", type=int, default=0)
 ap.add_argument("--threads", type=int, default=0)
+ap.add_argument("--no-events", action="store_true", help="queue the launches without per-dispatch events")
 ap.add_argument("--queued", type=int, default=1, help="launches queued back to back before the one that is read (1 = an isolated launch)")
 args = ap.parse_args()
 wl = bench.workload(args.config, args.envs)
@@ -35,11 +36,18 @@ for it in range(300):   # into the steady state of the episodes
     env.step_device(a[it % 8].data_ptr(), out.data_ptr(), stream=stream, packed=True)
 torch.cuda.synchronize()
 runs = []
+seq = None
 for it in range(40):
     # event-timed like bench.py: dockauv_time_steps on this very launch (the last of --queued back-to-back ones)
     # (--queued K: K launches queued by ONE C call, dockauv_time_steps, i.e. truly back to back on the stream -- launches
     # issued from Python arrive ~10 us apart and the GPU idles in between; `us` = their average event-timed duration)
-    us = env.time_steps_device(a[it % 8].data_ptr(), out.data_ptr(), steps=args.queued, stream=stream, packed=True)
+    if args.no_events:   # the same K launches without per-dispatch events (dockauv_step_sequence: what bench.py's timed region queues)
+        if seq is None:
+            seq = env.make_step_sequence([a[q % 8].data_ptr() for q in range(args.queued)], [out.data_ptr()] * args.queued, packed=True)
+        env.run_step_sequence(seq, stream=stream)
+        us = float("nan")
+    else:
+        us = env.time_steps_device(a[it % 8].data_ptr(), out.data_ptr(), steps=args.queued, stream=stream, packed=True)
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * (6 * G))()
     rc = lib.dockauv_debug_read_span(buf, G)
