@@ -93,12 +93,12 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:12]
 
 
-def pmc_entry(config_id: int, envs: int):
+def pmc_entry(config_id: int, envs: int, variant: str = ""):
     """Counters of the step kernel for this workload from the committed rocprofv3 --pmc passes (scripts/profile_round.sh
     -> profiles/pmc_counters.json): they are NOT measured in this run, so the entry carries its source."""
     path = os.path.join(ROOT, "profiles", "pmc_counters.json")
     try:
-        e = json.load(open(path)).get(f"config{config_id}_envs{envs}")
+        e = json.load(open(path)).get(f"config{config_id}{'_' + variant if variant else ''}_envs{envs}")
     except Exception:
         return None
     return e
@@ -202,14 +202,14 @@ def bound_of(config_id: int, envs: int, dense: bool = False) -> str:
     return "latency"
 
 
-def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha: str, dense: bool = False):
+def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha: str, dense: bool = False, variant: str = ""):
     bytes_per_launch = ALGO_BYTES[config_id] * envs
     achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
     r = {"bound": "hbm", "limited_by": bound_of(config_id, envs, dense), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
          "traffic": None, "kernel": "dockauv::step_kernel", "kernel_us": kernel_us,
          "algorithmic_bytes_per_env_step": ALGO_BYTES[config_id], "envs_per_launch": envs,
          "timing": f"hipExtLaunchKernel start/stop events on the launch stream, {n_timed} launches"}
-    e = pmc_entry(config_id, envs)
+    e = pmc_entry(config_id, envs, "dense" if dense else variant)
     if e:
         stale = e.get("kernel_sha") != ksha
         r["traffic"] = e.get("traffic_bytes")
@@ -417,7 +417,7 @@ def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, ke
     cl = closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400)
     res = {"workload": wl["name"], "envs": N, "value": N * args.steps / med, "unit": "env-steps/s",
            "ms_per_step": med / args.steps * 1e3, "reps": len(times), "kernel_us": kernel_us,
-           "roofline": roofline_of(config_id, N, kernel_us, kernel_launches, ksha),
+           "roofline": roofline_of(config_id, N, kernel_us, kernel_launches, ksha, variant="sorted" if layout == "vehicle_sorted" else ""),
            "closed_loop": cl, "obs_finite": finite}
     env.close()
     del actions, out
@@ -448,6 +448,9 @@ def main():
                     help="N > 1: what crosses xGMI per env and step.  f32 (default): the packed float32 rows, bit for bit; "
                          "bf16: observation columns as bfloat16 (half the bytes; reward / done stay float32).  The f32 line "
                          "also carries a `bf16_gather` sub-measurement of the same regions")
+    ap.add_argument("--only-ray-dense", type=int, default=0, metavar="CONFIG",
+                    help="profiling aid: run only the ray-dense measurement of config 3 or 4 and print its JSON")
+    ap.add_argument("--layout", default="", help="config 5: '' / interleaved (default) or vehicle_sorted")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--sweep", type=int, nargs="*", default=[262144, 1048576])
     args = ap.parse_args()
@@ -487,7 +490,10 @@ def main():
         backend = dist.get_backend()
 
     ksha = kernel_source_sha()
-    wl = workload(config_id, args.envs)
+    if args.only_ray_dense:
+        print(json.dumps(measure_ray_dense(args.only_ray_dense, args, torch, dev, local_rank, rank, ksha)), flush=True)
+        return
+    wl = workload(config_id, args.envs, args.layout)
     N = wl["envs"]
     env = make_env(wl, local_rank, rank, args.threads)
     n_obs, n_u = env.n_observations, env.n_u

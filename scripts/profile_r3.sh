@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-2 profiles (produced on the GPU box; copy gpurun_out/prof_r2 -> profiles/r2).  For each BASELINE config:
+# Round-3 profiles (produced on the GPU box; copy gpurun_out/prof_r3 -> profiles/r3).  For each BASELINE config:
 #   kernel_stats.csv   rocprofv3 --kernel-trace --stats of bench.py (average duration of dockauv::step_kernel)
 #   pmc_summary.txt    FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs), corrected with the calibration copy kernel
 #   sq_summary.txt     SQ instruction counters (own --pmc pass)
 # and pmc_counters.json, which bench.py reads for roofline.traffic / valu_frac (entries carry their source + kernel sha).
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-ROOT=$GRAFT_REPO_ROOT/gpurun_out/prof_r2
+ROOT=$GRAFT_REPO_ROOT/gpurun_out/prof_r3
 rm -rf $ROOT; mkdir -p $ROOT/calib
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 scripts/micro/fetch_calib.hip -o $ROOT/calib/fetch_calib 2> /dev/null
 $ROOT/calib/fetch_calib 1048576 > $ROOT/calib/calib.txt
@@ -45,7 +45,11 @@ prof config2 --config 2
 prof config3 --config 3
 prof config4 --config 4
 prof config5 --config 5
+prof config5_sorted --config 5 --layout vehicle_sorted
+prof config3_dense --only-ray-dense 3
+prof config4_dense --only-ray-dense 4
 prof config2_1M --config 2 --envs 1048576 --steps 200 --warmup 20
+prof config3_1M --config 3 --envs 1048576 --steps 200 --warmup 20
 python3 - $ROOT <<'PY'
 import json, os, sys
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
@@ -54,8 +58,9 @@ root = sys.argv[1]
 sha = bench.kernel_source_sha()
 out = {}
 for name, key in (("config2", "config2_envs4096"), ("config3", "config3_envs65536"), ("config4", "config4_envs32768"),
-                  ("config5", "config5_envs65536"), ("config2_1M", "config2_envs1048576")):
-    e = {"source": f"profiles/r2/{name}/", "kernel_sha": sha}
+                  ("config5", "config5_envs65536"), ("config5_sorted", "config5_sorted_envs65536"), ("config3_dense", "config3_dense_envs65536"),
+                  ("config4_dense", "config4_dense_envs32768"), ("config2_1M", "config2_envs1048576"), ("config3_1M", "config3_envs1048576")):
+    e = {"source": f"profiles/r3/{name}/", "kernel_sha": sha}
     try:
         d = json.loads(open(os.path.join(root, name, "pmc_summary.txt")).read().strip().splitlines()[-1])
         e.update(traffic_bytes=d["traffic_bytes"], read_bytes=d["read_bytes"], write_bytes=d["write_bytes"])
