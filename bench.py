@@ -171,7 +171,8 @@ def make_env(wl, local_rank: int, rank: int, threads: int):
     from gym_dockauv_amd.envs.batched import BatchedDocking3d
     from gym_dockauv_amd import _capi
     env = BatchedDocking3d(wl["cfg"], num_envs=wl["envs"], scenario=wl["scenario"], device=local_rank, precision="f32",
-                           reset_mode="device", device_seed=0x5EED0000 + rank, rng="batched", vehicles=wl["vehicles"],
+                           reset_mode=os.environ.get("DOCKAUV_BENCH_RESET_MODE", "device"),   # (diagnostic override: "none")
+                           device_seed=0x5EED0000 + rank, rng="batched", vehicles=wl["vehicles"],
                            threads_per_group=threads)
     env._gen = np.random.default_rng(1000 + rank)
     env.reset()

@@ -89,5 +89,10 @@ worst = np.nanargmax(tt, axis=1)
 sel = rel[np.arange(rel.shape[0]), worst]          # [launch, stamp]
 print("  slowest sampled group of each launch, medians: " + "  ".join(f"{nm.split()[0]}@{np.nanmedian(sel[:, i]):.0f}" for i, nm in
       ((2, "landed"), (3, "rk"), (14, "publish"), (15, "records"), (4, "raydone"), (5, "navobs"), (8, "wb"), (9, "end")) if not np.all(np.isnan(sel[:, i]))))
+arr_w = [np.nanmedian(sel[:, 24 + w]) for w in range(8)]
+if not all(np.isnan(a_) for a_ in arr_w):
+    print("  slowest sampled group of each launch: arrival of (physical) waves 0.. at the barrier behind the ray stage: "
+          + "  ".join("-" if np.isnan(a_) else f"{a_:.0f}" for a_ in arr_w)
+          + f";  resetter entered@{np.nanmedian(sel[:, 7]):.0f}  second wave: ray stage entered@{np.nanmedian(sel[:, 10]):.0f} passes done@{np.nanmedian(sel[:, 23]):.0f}")
 print(f"  total {np.nanmedian(total):.0f} ticks")
 env.close()
