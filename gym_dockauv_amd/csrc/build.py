@@ -26,11 +26,23 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wal
 PER_SOURCE_FLAGS = {"dockauv_kernels_f64.hip": ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0"]}
 
 
+# Test library with ONE injected fault (never the product): the float32 kernels built with
+# -DDOCKAUV_FAULT_INJECT_DROP_NAV_FLAG=1 (group 0's integrating wave never raises its hand-over flag), linked with the
+# product's other objects.  tests/test_gpu_status.py uses it to watch a bounded wait give up, the grid drain and
+# DOCKAUV_E_KERNEL reach the host.
+FAULT_LIB = os.path.join(LIB_DIR, "libdockauv_faultinject.so")
+FAULT_SRC, FAULT_FLAGS = "dockauv_kernels_f32.hip", ["-DDOCKAUV_FAULT_INJECT_DROP_NAV_FLAG=1"]
+
+
 def up_to_date() -> bool:
-    if not os.path.exists(OUT):
-        return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(os.path.join(HERE, d)) <= t for d in DEPS + ["build.py"])
+    variant = os.environ.get("DOCKAUV_LIB_NAME") is not None      # (scripts/build_variant.py: no fault library)
+    for lib in ([OUT] if variant else [OUT, FAULT_LIB]):
+        if not os.path.exists(lib):
+            return False
+        t = os.path.getmtime(lib)
+        if not all(os.path.getmtime(os.path.join(HERE, d)) <= t for d in DEPS + ["build.py"]):
+            return False
+    return True
 
 
 def build(force: bool = False, verbose: bool = False, extra=()) -> str:
@@ -48,6 +60,13 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, obj, subprocess.Popen(cmd, cwd=HERE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    fault = None
+    if os.environ.get("DOCKAUV_LIB_NAME") is None and not extra:   # the product build also makes the fault-injection test library
+        fobj = os.path.join(obj_dir, "dockauv_kernels_f32_faultinject.o")
+        cmd = [HIPCC, *cflags, *FAULT_FLAGS, "-c", FAULT_SRC, "-o", fobj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        fault = (fobj, subprocess.Popen(cmd, cwd=HERE, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     objs = []
     for src, obj, p in procs:
         out, _ = p.communicate()
@@ -62,6 +81,18 @@ def build(force: bool = False, verbose: bool = False, extra=()) -> str:
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
         raise RuntimeError("hipcc failed linking libdockauv.so")
+    if fault is not None:
+        fobj, p = fault
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out)
+            raise RuntimeError("hipcc failed on the fault-injection build of " + FAULT_SRC)
+        fobjs = [fobj if os.path.basename(o) == FAULT_SRC.replace(".hip", ".o") else o for o in objs]
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *fobjs, "-o", FAULT_LIB], cwd=HERE,
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("hipcc failed linking libdockauv_faultinject.so")
     return OUT
 
 
