@@ -209,7 +209,7 @@ def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha:
     r = {"bound": "hbm", "limited_by": bound_of(config_id, envs, dense), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
          "traffic": None, "kernel": "dockauv::step_kernel", "kernel_us": kernel_us,
          "algorithmic_bytes_per_env_step": ALGO_BYTES[config_id], "envs_per_launch": envs,
-         "timing": f"hipExtLaunchKernel start/stop events on the launch stream, {n_timed} launches"}
+         "timing": (KERNEL_TIMING + f"; {n_timed} launches") if isinstance(n_timed, int) else str(n_timed)}
     e = pmc_entry(config_id, envs, "dense" if dense else variant)
     if e:
         stale = e.get("kernel_sha") != ksha
@@ -232,20 +232,45 @@ def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha:
     return r
 
 
-def timed_regions(run, steps, warmup_steps, warm_i0, min_seconds, max_reps, sync, barrier, reduce_max):
+def timed_regions(run, steps, warmup_steps, warm_i0, min_seconds, max_reps, sync, barrier, reduce_max, event_ms=None, torch=None):
     """Warm up, then time regions of EXACTLY `steps` steps (barrier + synchronize on both sides, max over ranks) until
-    `min_seconds` have been measured.  Returns the list of region durations."""
+    `min_seconds` have been measured.  Returns the list of region durations (host clock).  event_ms (a list): each
+    region is also bracketed by two HIP events recorded on the launch stream (torch's current stream: the one the steps are
+    queued on); their elapsed times in ms are appended to it."""
     if warmup_steps > 0:
         run(warmup_steps, warm_i0)
     times = []
     while True:
         sync(); barrier(); sync()
+        if event_ms is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         t0 = time.perf_counter()
         run(steps, warm_i0 + warmup_steps)
+        if event_ms is not None:
+            ev1.record()
         sync(); barrier(); sync()
         times.append(reduce_max(time.perf_counter() - t0))
+        if event_ms is not None:
+            event_ms.append(ev0.elapsed_time(ev1))
         if sum(times) >= min_seconds or len(times) >= max_reps:
             return times
+
+
+KERNEL_TIMING = ("HIP events recorded on the launch stream around each timed region of K launches queued back to back by one "
+                 "dockauv_step_sequence call: median region time / K = the average launch duration, launch boundary included "
+                 "(an upper bound of the kernel's own duration; rocprofv3's queued dispatches report the same quantity)")
+
+
+def isolated_kernel_us(env, actions, out, ring, stream, torch, launches):
+    """The older measure (--isolated-kernel-timing): start / stop events attached to single dispatches launched one by one
+    with a host synchronisation in between (dockauv_time_steps).  It carries what an isolated launch pays on top: XCDs
+    that start up to ~2 us late after an idle gap, and with per-dispatch events XCD 0 lagging 0.6-0.8 us."""
+    us = 0.0
+    for i in range(launches):
+        us += env.time_steps_device(actions[i % ring].data_ptr(), out.data_ptr(), steps=1, stream=stream, packed=True)
+    torch.cuda.synchronize()
+    return us / launches
 
 
 def closed_loop_rate(env, torch, dev, N, n_obs, n_u, steps):
@@ -358,24 +383,23 @@ def measure_ray_dense(config_id, args, torch, dev, local_rank, rank, ksha):
     place_ray_dense(env, rng)
     env.run_step_sequence(seq, stream=stream)
     torch.cuda.synchronize()
-    times, act_end = [], []
+    times, act_end, ev_ms = [], [], []
     while sum(times) < args.min_seconds / 4 and len(times) < args.max_reps:
         place_ray_dense(env, rng)
         env.step_device(hold.data_ptr(), out.data_ptr(), stream=stream, packed=True)
         torch.cuda.synchronize()
         act0 = active_fraction()[0]
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         t0 = time.perf_counter()
         env.run_step_sequence(seq, stream=stream)
+        ev1.record()
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
+        ev_ms.append(ev0.elapsed_time(ev1))
         act_end.append(active_fraction()[0])
     med = statistics.median(times)
-    place_ray_dense(env, rng)
-    kernel_us, n_k = 0.0, 200
-    for i in range(n_k):
-        kernel_us += env.time_steps_device(hold.data_ptr(), out.data_ptr(), steps=1, stream=stream, packed=True)
-    kernel_us /= n_k
-    torch.cuda.synchronize()
+    kernel_us, n_k = statistics.median(ev_ms) / K * 1e3, len(ev_ms) * K
     res = {"workload": wl["name"] + " -- ray-dense operating point", "envs": N, "value": N * K / med, "unit": "env-steps/s",
            "ms_per_step": med / K * 1e3, "reps": len(times), "steps_per_region": K, "kernel_us": kernel_us,
            "active_fraction": {"what": "share of the envs with at least one ray that hits within range (clamped distance < max_dist)",
@@ -406,20 +430,20 @@ def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, ke
             cache[key] = env.make_step_sequence([actions[i % RING].data_ptr() for i in range(i0, i0 + n)], [out.data_ptr()] * n, packed=True)
         env.run_step_sequence(cache[key], stream=stream)
 
+    ev_ms = []
     times = timed_regions(run, args.steps, args.warmup, 0, args.min_seconds / 2, args.max_reps, torch.cuda.synchronize,
-                          lambda: None, lambda x: x)
+                          lambda: None, lambda x: x, event_ms=ev_ms, torch=torch)
     med = statistics.median(times)
-    kernel_us = 0.0
-    for i in range(kernel_launches):
-        kernel_us += env.time_steps_device(actions[i % RING].data_ptr(), out.data_ptr(), steps=1, stream=stream, packed=True)
-    kernel_us /= kernel_launches
-    torch.cuda.synchronize()
+    kernel_us = statistics.median(ev_ms) / args.steps * 1e3
     finite = bool(torch.isfinite(out).all().item())
+    iso = isolated_kernel_us(env, actions, out, RING, stream, torch, kernel_launches) if args.isolated_kernel_timing else None
     cl = closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400)
     res = {"workload": wl["name"], "envs": N, "value": N * args.steps / med, "unit": "env-steps/s",
            "ms_per_step": med / args.steps * 1e3, "reps": len(times), "kernel_us": kernel_us,
-           "roofline": roofline_of(config_id, N, kernel_us, kernel_launches, ksha, variant="sorted" if layout == "vehicle_sorted" else ""),
+           "roofline": roofline_of(config_id, N, kernel_us, len(ev_ms) * args.steps, ksha, variant="sorted" if layout == "vehicle_sorted" else ""),
            "closed_loop": cl, "obs_finite": finite}
+    if iso is not None:
+        res["kernel_us_isolated_launches"] = iso
     env.close()
     del actions, out
     return res
@@ -449,6 +473,8 @@ def main():
                     help="N > 1: what crosses xGMI per env and step.  f32 (default): the packed float32 rows, bit for bit; "
                          "bf16: observation columns as bfloat16 (half the bytes; reward / done stay float32).  The f32 line "
                          "also carries a `bf16_gather` sub-measurement of the same regions")
+    ap.add_argument("--isolated-kernel-timing", action="store_true",
+                    help="also report kernel_us_isolated_launches: per-dispatch events on launches issued one by one")
     ap.add_argument("--only-ray-dense", type=int, default=0, metavar="CONFIG",
                     help="profiling aid: run only the ray-dense measurement of config 3 or 4 and print its JSON")
     ap.add_argument("--layout", default="", help="config 5: '' / interleaved (default) or vehicle_sorted")
@@ -601,8 +627,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    region_ev_ms = []
     times = timed_regions(run, args.steps, max(0, args.warmup - n_verify), n_verify, args.min_seconds, args.max_reps,
-                          torch.cuda.synchronize, barrier, reduce_max)
+                          torch.cuda.synchronize, barrier, reduce_max, event_ms=None if use_dist else region_ev_ms, torch=torch)
     if transport == "p2p":
         # a stamp that did not arrive within the spin bound voids the regions on every rank: measure again over RCCL
         late = torch.tensor([stepper.gather.timed_out()], device=dev, dtype=torch.int64)
@@ -680,12 +707,22 @@ def main():
 
     # roofline of the dominant (only) kernel: per-dispatch start/stop events on the launch stream, cycling through
     # the same action ring as the timed region
+    # single GPU: the timed regions themselves, bracketed by HIP events on the launch stream (region time / K); N > 1: the
+    # regions contain the gather, so the kernel is timed by per-dispatch events on launches of its own
     n_timed = min(max(args.steps, 256), 1024)
-    kernel_us = 0.0
-    for i in range(n_timed):
-        kernel_us += env.time_steps_device(actions[i % RING].data_ptr(), out_l.data_ptr(), steps=1, stream=stream, packed=pack_mode)
-    kernel_us /= n_timed
-    torch.cuda.synchronize()
+    kernel_us_iso = None
+    if use_dist or args.isolated_kernel_timing:
+        kernel_us_iso = 0.0
+        for i in range(n_timed):
+            kernel_us_iso += env.time_steps_device(actions[i % RING].data_ptr(), out_l.data_ptr(), steps=1, stream=stream, packed=pack_mode)
+        kernel_us_iso /= n_timed
+        torch.cuda.synchronize()
+    if use_dist:
+        kernel_us = kernel_us_iso
+        n_timed = f"hipExtLaunchKernel start/stop events on {n_timed} single dispatches of the step kernel (the regions of an N > 1 run contain the gather)"
+    else:
+        kernel_us = statistics.median(region_ev_ms) / args.steps * 1e3
+        n_timed = len(region_ev_ms) * args.steps
     last = stepper.bufs[0]
     if pack_mode == "bf16":
         o16, r16, d16_ = ShardedStepper.split_bf16(last, n_obs)
@@ -708,11 +745,18 @@ def main():
             e2.reset()
             a2 = torch.rand((4, n_big, n_u), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
             o2 = torch.zeros((n_big, n_obs + 2), device=dev, dtype=torch.float32)
-            for r in range(8):
-                e2.step_device(a2[r % 4].data_ptr(), o2.data_ptr(), stream=stream, packed=True)
+            seq2 = e2.make_step_sequence([a2[r % 4].data_ptr() for r in range(20)], [o2.data_ptr()] * 20, packed=True)
+            e2.run_step_sequence(seq2, stream=stream)
             torch.cuda.synchronize()
-            us = sum(e2.time_steps_device(a2[r % 4].data_ptr(), o2.data_ptr(), steps=10, stream=stream, packed=True) for r in range(8)) / 8
-            torch.cuda.synchronize()
+            ev = []
+            for r in range(6):
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                e2.run_step_sequence(seq2, stream=stream)
+                ev1.record()
+                torch.cuda.synchronize()
+                ev.append(ev0.elapsed_time(ev1) / 20 * 1e3)
+            us = statistics.median(ev)
             gbps = ALGO_BYTES[config_id] * n_big / (us * 1e-6) / 1e9
             sweep.append({"envs": n_big, "kernel_us": us, "env_steps_per_s_kernel": n_big / (us * 1e-6),
                           "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS})
@@ -777,6 +821,8 @@ def main():
                        "kernel_source_sha": ksha},
             "roofline": roofline_of(config_id, N, kernel_us, n_timed, ksha),
         }
+        if kernel_us_iso is not None and not use_dist:
+            out["kernel_us_isolated_launches"] = kernel_us_iso
         if closed:
             out["closed_loop"] = closed
         if alone:
