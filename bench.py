@@ -437,7 +437,7 @@ def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, ke
     kernel_us = statistics.median(ev_ms) / args.steps * 1e3
     finite = bool(torch.isfinite(out).all().item())
     iso = isolated_kernel_us(env, actions, out, RING, stream, torch, kernel_launches) if args.isolated_kernel_timing else None
-    cl = closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400)
+    cl = None if args.no_closed_loop else closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400)
     res = {"workload": wl["name"], "envs": N, "value": N * args.steps / med, "unit": "env-steps/s",
            "ms_per_step": med / args.steps * 1e3, "reps": len(times), "kernel_us": kernel_us,
            "roofline": roofline_of(config_id, N, kernel_us, len(ev_ms) * args.steps, ksha, variant="sorted" if layout == "vehicle_sorted" else ""),
@@ -473,6 +473,9 @@ def main():
                     help="N > 1: what crosses xGMI per env and step.  f32 (default): the packed float32 rows, bit for bit; "
                          "bf16: observation columns as bfloat16 (half the bytes; reward / done stay float32).  The f32 line "
                          "also carries a `bf16_gather` sub-measurement of the same regions")
+    ap.add_argument("--no-closed-loop", action="store_true",
+                    help="skip the closed-loop sub-measurement (its launches are issued from Python one by one: profiling runs "
+                         "use this so that rocprofv3's per-kernel average covers the queued launches of the timed regions only)")
     ap.add_argument("--isolated-kernel-timing", action="store_true",
                     help="also report kernel_us_isolated_launches: per-dispatch events on launches issued one by one")
     ap.add_argument("--only-ray-dense", type=int, default=0, metavar="CONFIG",
@@ -731,7 +734,7 @@ def main():
     else:
         finite = bool(torch.isfinite(last).all().item())
         n_done = int((out_l[:, n_obs + 1] > 0.5).sum().item())
-    closed = closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400) if world == 1 and not use_dist else None
+    closed = closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400) if world == 1 and not use_dist and not args.no_closed_loop else None
 
     sweep = []
     if world == 1 and not args.no_sweep and not args.envs:

@@ -17,14 +17,14 @@ prof() {   # name, bench args...
   local name=$1; shift
   local OUT=$ROOT/$name
   mkdir -p $OUT
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu --no-sweep --no-configs --steps 1000 --warmup 200 --min-seconds 0.05 "$@" > $OUT/bench_line.json 2> $OUT/bench_trace.err || { tail -5 $OUT/bench_trace.err; return 1; }
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu --no-sweep --no-configs --no-closed-loop --steps 1000 --warmup 200 --min-seconds 0.05 "$@" > $OUT/bench_line.json 2> $OUT/bench_trace.err || { tail -5 $OUT/bench_trace.err; return 1; }
   find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
   # the same trace per dispatch: launches queued back to back (the timed regions) against launches after an idle gap
   # (the per-dispatch event timing loop) -- rocprofv3's average mixes the two
   python3 scripts/diag/trace_split.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) > $OUT/kernel_trace_split.txt 2>&1
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --no-cpu --no-sweep --no-configs --steps 100 --warmup 20 --min-seconds 0.001 "$@" > /dev/null 2> $OUT/pmc_fetch.err || tail -3 $OUT/pmc_fetch.err
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --no-cpu --no-sweep --no-configs --steps 100 --warmup 20 --min-seconds 0.001 "$@" > /dev/null 2> $OUT/pmc_write.err || tail -3 $OUT/pmc_write.err
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- python3 bench.py --no-cpu --no-sweep --no-configs --steps 100 --warmup 20 --min-seconds 0.001 "$@" > /dev/null 2> $OUT/pmc_sq.err || tail -3 $OUT/pmc_sq.err
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --no-cpu --no-sweep --no-configs --no-closed-loop --steps 100 --warmup 20 --min-seconds 0.001 "$@" > /dev/null 2> $OUT/pmc_fetch.err || tail -3 $OUT/pmc_fetch.err
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --no-cpu --no-sweep --no-configs --no-closed-loop --steps 100 --warmup 20 --min-seconds 0.001 "$@" > /dev/null 2> $OUT/pmc_write.err || tail -3 $OUT/pmc_write.err
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- python3 bench.py --no-cpu --no-sweep --no-configs --no-closed-loop --steps 100 --warmup 20 --min-seconds 0.001 "$@" > /dev/null 2> $OUT/pmc_sq.err || tail -3 $OUT/pmc_sq.err
   python3 scripts/summarize_pmc.py $OUT $ROOT/calib > $OUT/pmc_summary.txt 2>&1
   python3 - $OUT <<'PY' > $OUT/sq_summary.txt
 import csv, glob, os, sys, collections, json
