@@ -19,6 +19,8 @@ Workloads (--config):
   3  BlueROV2, 16-beam fan vs 8 spheres, 65 536 envs/GPU          [default at N = 1: the largest single-GPU config]
   4  LAUV, ObstaclesDocking3d (5 capsules, 63 rays), t_step_size 0.02, 32 768 envs/GPU      [default at N > 1]
   5  BlueROV2/LAUV 50/50, ObstaclesCurrentDocking3d, current speed U(0,1), t_step_size 0.02, 65 536 envs/GPU
+`roofline.kernel_us` = HIP events recorded on the launch stream around each timed region / K (the average launch duration,
+launch boundary included; `--isolated-kernel-timing` adds the older per-dispatch events on launches issued one by one).
 At N = 1 the line also carries `configs`: the same measurement (open-loop rate, kernel duration by HIP events,
 roofline, closed-loop rate) of config 2 at 4 096 envs and of the per-GPU shards of configs 4 and 5.
 """
