@@ -570,6 +570,7 @@ def gen_trajectories():
              lambda rs: ctrl_random(rs), cfg_over=dict(lauv, max_timesteps=90), act_seed=14)
     gen_mixed_partner()
     gen_near_obstacles()
+    gen_lauv_collision()
 
 
 def gen_mixed_partner():
@@ -593,6 +594,24 @@ def gen_near_obstacles():
     run_traj("traj_ObstaclesCurrentDocking3d_bluerov2_h002_near", "ObstaclesCurrentDocking3d", "BlueROV2", 73, 240,
              lambda rs: ctrl_goto(rs, noise=0.3), cfg_over=near, act_seed=18,
              post_reset=place_near_obstacle(np.random.RandomState(173)))
+
+
+def ctrl_ram(rs):
+    """full thrust straight ahead (LAUV: fins neutral), small noise: drives a vehicle placed in front of a capsule into it"""
+    def f(env):
+        n_u = env.auv.u_bound.shape[0]
+        a = rs.normal(scale=0.05, size=n_u)
+        a[0] = 1.0
+        return a
+    return f
+
+
+def gen_lauv_collision():
+    """Round 3: the LAUV kernels' collision condition with the fan full of hits -- the vehicle starts 2.8-3.2 m from a capsule
+    axis (collision at <= 2 m), facing it, full thrust."""
+    run_traj("traj_ObstaclesDocking3d_lauv_ram", "ObstaclesDocking3d", "LAUV", 81, 420, ctrl_ram,
+             cfg_over={"t_step_size": 0.02, "max_timesteps": 400}, act_seed=19,
+             post_reset=place_near_obstacle(np.random.RandomState(181), dist=(2.8, 3.2)))
 
 
 def gen_radar_layout():
@@ -627,6 +646,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if "--near-only" in sys.argv:             # added in round 3; the other fixtures are unchanged
         gen_near_obstacles()
+        sys.exit(0)
+    if "--ram-only" in sys.argv:              # added in round 3
+        gen_lauv_collision()
         sys.exit(0)
     gen_constants()
     gen_state_dot()

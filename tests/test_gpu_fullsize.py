@@ -7,7 +7,7 @@ exclusion rules as the teacher-forced tests of tests/test_gpu_parity.py: 1e-5 on
 
   config 2: BlueROV2 SimpleDocking3d,            4 096 envs   <- traj_config1_simple_bluerov2
   config 3: BlueROV2 + 16-beam fan + 8 spheres, 65 536 envs   <- traj_SphereDocking3d_bluerov2_fan16(_random)
-  config 4: LAUV ObstaclesDocking3d, h = 0.02,  32 768 envs   <- traj_ObstaclesDocking3d_lauv_goto, ..._lauv_near
+  config 4: LAUV ObstaclesDocking3d, h = 0.02,  32 768 envs   <- traj_ObstaclesDocking3d_lauv_goto, ..._lauv_near, ..._lauv_ram
   config 5: BlueROV2 / LAUV interleaved 50/50, ObstaclesCurrentDocking3d, h = 0.02, 65 536 envs (VK_MIXED kernel)
             <- traj_ObstaclesCurrentDocking3d_bluerov2_h002_random (even envs) + ..._lauv_random (odd envs), and the
                ..._near pair (vehicles next to an obstacle: 30-50 % of the rays in range)
@@ -101,11 +101,14 @@ MIXED_PAIRS = {
 }
 
 
-@pytest.mark.parametrize("name", ["traj_ObstaclesDocking3d_lauv_goto", "traj_ObstaclesDocking3d_lauv_near"])
+@pytest.mark.parametrize("name", ["traj_ObstaclesDocking3d_lauv_goto", "traj_ObstaclesDocking3d_lauv_near",
+                                  "traj_ObstaclesDocking3d_lauv_ram"])
 def test_config4_full_size(name):
     g = H.load(name)
-    if name.endswith("_near"):   # the point of this fixture: the LAUV 63-ray eight-wave kernel with rays that hit
+    if not name.endswith("_goto"):   # the point of these fixtures: the LAUV 63-ray eight-wave kernel with rays that hit
         assert float((g["ray_dist"] < float(g["meta_radar_max_dist"])).mean()) >= 0.15
+    if name.endswith("_ram"):        # ... and with collisions (full thrust into a capsule)
+        assert int(g["conditions"][:, 4].sum()) >= 3
     run_tiled([name], 32768)
 
 
