@@ -64,3 +64,31 @@ def test_bf16_rows_are_the_rounded_float32_rows(config_id, n_envs):
     finally:
         e32.close()
         e16.close()
+
+
+def test_sharded_env_bf16_gather_single_rank():
+    """ShardedTorchDocking3d(gather_dtype="bf16") on one rank: the observation view it hands the learner is the bfloat16
+    rounding of what the float32 env returns from the same state; reward / done identical."""
+    import torch
+    from gym_dockauv_amd.envs.torch_env import ShardedTorchDocking3d, TorchDocking3d
+    N = 1024
+    e16 = ShardedTorchDocking3d(num_envs=N, scenario="ObstaclesCurrentDocking3d", device=0, device_seed=9, host_seed=4, gather_dtype="bf16")
+    e32 = TorchDocking3d(num_envs=N, scenario="ObstaclesCurrentDocking3d", device=0, device_seed=9)
+    try:
+        e32.batch._gen = np.random.default_rng(4)
+        e16.reset()
+        e32.reset()
+        g = torch.Generator(device=e32.device)
+        g.manual_seed(3)
+        for t in range(30):
+            a = (torch.rand((N, e32.n_u), device=e32.device, generator=g) * 2 - 1).contiguous()
+            o16, r16, d16 = e16.step(a)
+            o32, r32, d32 = e32.step(a)
+            assert o16.dtype == torch.bfloat16 and tuple(o16.shape) == (N, e32.n_obs)
+            assert torch.equal(o16, o32.to(torch.bfloat16)), f"step {t}"     # torch rounds to nearest even as well
+            assert torch.equal(r16, r32) and torch.equal(d16, d32)
+        with pytest.raises(ValueError):
+            ShardedTorchDocking3d(num_envs=64, device=0, gather_dtype="bf16", transport="p2p")
+    finally:
+        e16.close()
+        e32.close()
