@@ -438,7 +438,9 @@ def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, ke
     med = statistics.median(times)
     kernel_us = statistics.median(ev_ms) / args.steps * 1e3
     finite = bool(torch.isfinite(out).all().item())
-    iso = isolated_kernel_us(env, actions, out, RING, stream, torch, kernel_launches) if args.isolated_kernel_timing else None
+    iso = isolated_kernel_us(env, actions, out, RING, stream, torch, kernel_launches) if (args.isolated_kernel_timing or args.steps < 100) else None
+    if args.steps < 100:
+        kernel_us = iso
     cl = None if args.no_closed_loop else closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400)
     res = {"workload": wl["name"], "envs": N, "value": N * args.steps / med, "unit": "env-steps/s",
            "ms_per_step": med / args.steps * 1e3, "reps": len(times), "kernel_us": kernel_us,
@@ -716,15 +718,17 @@ def main():
     # regions contain the gather, so the kernel is timed by per-dispatch events on launches of its own
     n_timed = min(max(args.steps, 256), 1024)
     kernel_us_iso = None
-    if use_dist or args.isolated_kernel_timing:
+    short_regions = args.steps < 100   # (a region of a few launches is dominated by its first launch after an idle gap)
+    if use_dist or args.isolated_kernel_timing or short_regions:
         kernel_us_iso = 0.0
         for i in range(n_timed):
             kernel_us_iso += env.time_steps_device(actions[i % RING].data_ptr(), out_l.data_ptr(), steps=1, stream=stream, packed=pack_mode)
         kernel_us_iso /= n_timed
         torch.cuda.synchronize()
-    if use_dist:
+    if use_dist or short_regions:
         kernel_us = kernel_us_iso
-        n_timed = f"hipExtLaunchKernel start/stop events on {n_timed} single dispatches of the step kernel (the regions of an N > 1 run contain the gather)"
+        n_timed = (f"hipExtLaunchKernel start/stop events on {n_timed} single dispatches of the step kernel ("
+                   + ("the regions of an N > 1 run contain the gather" if use_dist else f"--steps {args.steps}: regions too short to average over") + ")")
     else:
         kernel_us = statistics.median(region_ev_ms) / args.steps * 1e3
         n_timed = len(region_ev_ms) * args.steps
