@@ -423,7 +423,13 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
     // the least total work.
     if (c.threads_per_group > 0) h->threads = c.threads_per_group;
     else if (!h->has_rays) h->threads = c.n_envs <= 65536 ? 256 : (c.n_envs <= 131072 ? 128 : 64);
-    else h->threads = ((long)h->n_rays * (c.max_capsules + c.max_spheres) >= 256 && c.n_envs <= 32768) ? 512 : 256;
+    else {
+        // (light fans -- config 3's 16 beams x 8 spheres -- beyond ~8 rounds of resident groups: one wave per group does
+        // the least total work there as well: 1 048 576 envs 171.5 -> 143.6 us, 524 288 envs 68.6 -> 66.8; heavy fans
+        // stay at four waves: config 4 at 1 048 576 envs 250 us against 319; scripts/diag/threads_large.sh)
+        const long tests = (long)h->n_rays * (c.max_capsules + c.max_spheres);
+        h->threads = (tests >= 256 && c.n_envs <= 32768) ? 512 : ((tests < 256 && c.n_envs > 524288) ? 64 : 256);
+    }
     if (c.n_vehicles == 2) {
         if (!(c.vehicle[0].kind == DOCKAUV_VEH_CONSTB && b_is_diagonal(c.vehicle[0]) && c.vehicle[1].kind == DOCKAUV_VEH_LAUV)) {
             delete h;

@@ -4,6 +4,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r3
 bash scripts/profile_r3.sh > gpurun_out/prof_r3.log 2>&1 || { tail -20 gpurun_out/prof_r3.log; exit 1; }
 grep -E "^== |step_kernel" gpurun_out/prof_r3.log | cut -c1-150
+cp gpurun_out/prof_r3/pmc_counters.json profiles/pmc_counters.json   # (the box's copy: the default line below cites the counters just taken)
 timeout -k 10 600 python bench.py > gpurun_out/r3/bench_default_unprofiled.json 2> gpurun_out/r3/bench_default.err || { tail -5 gpurun_out/r3/bench_default.err; exit 1; }
 python - <<'PY'
 import json
