@@ -3,6 +3,7 @@
 bench.py -- env-steps/s of the batched docking3d step() on N MI355X (BASELINE.json metric), one process per GPU.
 
   python bench.py --gpus 1 --steps K --warmup W                       (defaults finish in a few minutes)
+  python bench.py --gpus N --steps K --warmup W                       (N > 1 without a launcher: starts its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
@@ -453,6 +454,53 @@ def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, ke
     return res
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` started without a launcher: become one.  N child rank processes of this very command line
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) are started BEFORE this process imports torch
+    or makes any HIP call; rank 0's stdout -- the ONE JSON line -- is relayed, the other ranks' stdout goes to stderr.
+    Returns 0 only if every rank did; a rank that fails takes the others down (they would wait at the rendezvous)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: what RCCL needs on this driver)
+    base.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    children = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        children.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    import threading
+    chunks = []
+    drain = threading.Thread(target=lambda: chunks.append(children[0].stdout.read()), daemon=True)   # (a full pipe must not block rank 0)
+    drain.start()
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = children[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}: stopping the other ranks", file=sys.stderr, flush=True)
+                for q in pending:
+                    children[q].terminate()   # (exactly the processes started above)
+        if pending:
+            time.sleep(0.05)
+    drain.join(timeout=30)
+    out = b"".join(chunks).decode(errors="replace")
+    if rc == 0:
+        sys.stdout.write(out)
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(out)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -492,6 +540,10 @@ def main():
         print(cpu_baseline(workload(args.config or 3, 2), args.cpu_seconds)["value"])
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process becomes the launcher (nothing has touched the GPU yet)
+        sys.exit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -499,10 +551,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: start it as `python bench.py --gpus N` (it launches its own "
+                         "ranks) or as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    if world > 1 and os.environ.get("DOCKAUV_DIST_BACKEND", "nccl") == "gloo":
+        # rehearsal transport (several ranks on one GPU, or none: tests/test_bench_contract.py): the rendezvous needs no device,
+        # so it is made -- and proven by a collective -- before the first thing that does
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        assert int(t.item()) == world * (world + 1) // 2
+        print(f"[rank {rank}] rendezvous of {world} ranks complete (gloo)", file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+        raise SystemExit(f"[rank {rank}] bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     config_id = args.config or (3 if world == 1 else 4)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -518,7 +580,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         if os.environ.get("DOCKAUV_DIST_BACKEND", "nccl") == "gloo":
             # rehearsal only (scripts/bench_ranks_one_gpu.sh): several ranks on ONE GPU, which RCCL refuses
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            if not dist.is_initialized():   # (world > 1: made above, before the device check)
+                dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         backend = dist.get_backend()
@@ -838,6 +901,18 @@ def main():
             out["same_workload_without_gather"] = alone
         if bf16_gather:
             out["bf16_gather"] = bf16_gather
+        if use_dist:
+            # what the gather asks of the fabric: every rank sends its rows to each of the N - 1 others once per step
+            # (xGMI is point to point: one link per peer, ~64 GB/s per direction at its 153 GB/s bidirectional peak)
+            bpr = out["config"]["gather_bytes_per_rank_per_step"]
+            step_s = dt / args.steps
+            out["link_GBps_achieved"] = {
+                "per_rank_egress": bpr * (world - 1) / step_s / 1e9, "per_link_direction": bpr / step_s / 1e9,
+                "what": "gathered bytes per rank and step x (N - 1) peers / step time of this line (per link and direction: "
+                        "one rank's rows / step time); if the step time equals same_workload_without_gather's, the links "
+                        "are not what bounds it",
+                **({"bf16_per_rank_egress": bf16_gather["bytes_per_rank_per_step"] * (world - 1) / (bf16_gather["ms_per_step"] * 1e-3) / 1e9}
+                   if bf16_gather else {})}
         if sweep:
             out["sweep"] = sweep
         if world == 1 and not use_dist and not args.no_configs and not args.envs:

@@ -69,6 +69,32 @@ def test_committed_counters_belong_to_the_committed_kernel():
         assert d[key]["traffic_bytes"] > 0
 
 
+def test_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (the shape of the driver's N = 1 command) starts two rank processes
+    itself: both make the rendezvous (gloo here: no device needed for it) and get as far as the first thing that needs a
+    GPU; in this container that is where they stop, and the launcher hands the failure on."""
+    env = dict(os.environ, DOCKAUV_DIST_BACKEND="gloo", HIP_VISIBLE_DEVICES="")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    err = out.stderr
+    assert "launch N > 1 with" not in err
+    for r in (0, 1):
+        assert f"[rank {r}] rendezvous of 2 ranks complete" in err, err[-2000:]
+    import torch
+    if not torch.cuda.is_available():
+        assert out.returncode != 0 and "needs an MI355X" in err and out.stdout.strip() == ""
+        assert "stopping the other ranks" in err
+
+
+def test_world_size_must_match_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", HIP_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                         timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE = 2" in out.stderr
+
+
 @pytest.mark.gpu
 def test_default_line_has_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "200", "--warmup", "50", "--min-seconds", "0.05",
