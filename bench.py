@@ -43,7 +43,7 @@ ALGO_BYTES = {2: 356, 3: 420, 4: 460, 5: 482}   # algorithmic bytes per env-step
 HBM_PEAK_GBPS = 8000.0                           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_SIMD = 1024                                    # 256 CUs x 4 SIMDs
 CLOCK_MHZ = 2400.0                               # max shader clock (MI355X_MICROARCH.md)
-VALU_CYCLES_PER_INST = 4.0                       # issue slots a wave64 VALU instruction is priced at (x4)
+VALU_CYCLES_PER_INST = 4.0                       # secondary pricing of a wave64 VALU instruction (rounds 1-3: x4, overstates two-fold)
 VALU_CYCLES_MEASURED = 2.1                       # plain fp32 VALU instruction on a saturated SIMD, measured (scripts/micro/issue_rate.hip)
 
 
@@ -209,7 +209,9 @@ def bound_of(config_id: int, envs: int, dense: bool = False) -> str:
 def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha: str, dense: bool = False, variant: str = ""):
     bytes_per_launch = ALGO_BYTES[config_id] * envs
     achieved = bytes_per_launch / (kernel_us * 1e-6) / 1e9
-    r = {"bound": "hbm", "limited_by": bound_of(config_id, envs, dense), "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+    r = {"bound": "hbm", "limited_by": bound_of(config_id, envs, dense),
+         "limited_by_source": "design-time classification by config and batch size (DESIGN.md section 5): not derived from this run",
+         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
          "traffic": None, "kernel": "dockauv::step_kernel", "kernel_us": kernel_us,
          "algorithmic_bytes_per_env_step": ALGO_BYTES[config_id], "envs_per_launch": envs,
          "timing": (KERNEL_TIMING + f"; {n_timed} launches") if isinstance(n_timed, int) else str(n_timed)}
@@ -225,13 +227,15 @@ def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha:
             if stale:
                 r["valu_frac_note"] = "SQ_INSTS_VALU was counted on an earlier kernel version than this library: indicative only"
             cyc = kernel_us * CLOCK_MHZ
-            r["valu_frac"] = e["sq_insts_valu"] * VALU_CYCLES_PER_INST / (N_SIMD * cyc)
-            # the same count priced at what a saturated SIMD was MEASURED to need for a plain fp32 instruction
-            # (profiles/r2/issue_rate.txt: 8.4 cycles per instruction and wave at 4 waves per SIMD; packed, DPP and
-            # transcendental instructions cost 2-4 x that): a lower bound of the SIMDs' busy share
-            r["valu_frac_at_measured_issue_rate"] = e["sq_insts_valu"] * VALU_CYCLES_MEASURED / (N_SIMD * cyc)
-            r["valu_frac_inputs"] = {"SQ_INSTS_VALU_per_launch": e["sq_insts_valu"], "cycles_per_inst": VALU_CYCLES_PER_INST,
-                                     "cycles_per_inst_measured": VALU_CYCLES_MEASURED, "simds": N_SIMD, "kernel_cycles_at_2400MHz": cyc}
+            # share of the SIMDs' cycles spent issuing VALU instructions, priced at what a saturated SIMD was MEASURED to need
+            # for a plain fp32 wave64 instruction (2.1 cycles: 157 TFLOP/s / 1 024 SIMDs / 2.4 GHz = 64 flop per clock and SIMD;
+            # profiles/r2/issue_rate.txt; packed, DPP and transcendental instructions cost 2-4 x that) -- a lower bound of the
+            # busy share.  The x 4 pricing of rounds 1-3 (one instruction per 4 cycles) overstated it two-fold and stays as a
+            # secondary figure.
+            r["valu_frac"] = e["sq_insts_valu"] * VALU_CYCLES_MEASURED / (N_SIMD * cyc)
+            r["valu_frac_at_4_cycles_per_inst"] = e["sq_insts_valu"] * VALU_CYCLES_PER_INST / (N_SIMD * cyc)
+            r["valu_frac_inputs"] = {"SQ_INSTS_VALU_per_launch": e["sq_insts_valu"], "cycles_per_inst": VALU_CYCLES_MEASURED,
+                                     "cycles_per_inst_secondary": VALU_CYCLES_PER_INST, "simds": N_SIMD, "kernel_cycles_at_2400MHz": cyc}
     return r
 
 

@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdockauv.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_U = 8
 N_REWARDS = 13
 N_CONDITIONS = 5
@@ -110,6 +110,7 @@ SYMBOLS = [
     ("dockauv_step_sequence", C.c_int, [C.c_void_p, C.POINTER(StepIO), C.c_int, C.c_void_p]),
     ("dockauv_step_host", C.c_int, [C.c_void_p, C.POINTER(StepIO)]),
     ("dockauv_synchronize", C.c_int, [C.c_void_p]),
+    ("dockauv_poll_status", C.c_int, [C.c_void_p]),
     ("dockauv_trace_enable", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     ("dockauv_trace_steps", C.c_longlong, [C.c_void_p]),
     ("dockauv_trace_read", C.c_int, [C.c_void_p, C.c_longlong, C.c_int] + [C.c_void_p] * 8),

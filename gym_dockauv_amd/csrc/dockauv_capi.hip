@@ -46,6 +46,7 @@ struct dockauv_env_s {
     KernelArgs<float, 2> a32{};
     KernelArgs<double, 2> a64{};
     std::string err;
+    volatile unsigned int* status_host = nullptr;   // the kernels' sticky status word: pinned, host-coherent, mapped into the device
     hipStream_t last_stream = nullptr;
     // host-pointer step staging
     void* d_actions = nullptr;
@@ -64,7 +65,6 @@ struct dockauv_env_s {
         void* actions = nullptr; void* noise = nullptr; float* obs = nullptr; void* reward = nullptr;
         uint8_t* done = nullptr; void* terms = nullptr; uint8_t* cond = nullptr; void* nav = nullptr;
         void* raydist = nullptr; float* termobs = nullptr; void* statedot = nullptr;
-        unsigned int* status = nullptr;   // mirror of the kernels' sticky status word
         bool ready = false;
     } pin;
     std::vector<void*> pinned_allocs;
@@ -98,14 +98,14 @@ int fail(dockauv_handle h, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(h, DOCKAUV_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-// Sticky status word of the handle's kernels, read wherever the host has just synchronised with the stream (4 bytes;
-// no synchronisation of its own beyond the copy).  Non-zero = a step kernel gave up an internal wait: every result since
+// Sticky status word of the handle's kernels.  It lives in pinned host memory that the device maps (coherent): a kernel
+// that gives up a wait ORs its bit in over the bus (the failure path only), and the host reads the word with a plain load --
+// wherever it has just synchronised with the stream, and in dockauv_poll_status without any synchronisation at all (what a
+// device-resident rollout calls every few steps).  Non-zero = a step kernel gave up an internal wait: every result since
 // is invalid; the handle stays in that state (the caller destroys it).
 int check_status(dockauv_handle h) {
-    const unsigned int* sw = h->f64 ? h->a64.B.status : h->a32.B.status;
-    if (!sw) return 0;
-    unsigned int v = 0;
-    HIP_TRY(h, hipMemcpy(&v, sw, sizeof v, hipMemcpyDeviceToHost));
+    if (!h->status_host) return 0;
+    const unsigned int v = *h->status_host;
     if (v != 0)
         return fail(h, DOCKAUV_E_KERNEL, "step kernel status 0x%x: a tail role timed out waiting for its group's integrating wave; "
                     "results since are invalid, destroy the handle", v);
@@ -332,7 +332,9 @@ extern "C" {
 int dockauv_abi_version(void) { return DOCKAUV_ABI_VERSION; }
 
 const char* dockauv_build_info(void) {
-    return "libdockauv gfx950 (HIP), abi " "2" ", built " __DATE__ " " __TIME__;
+#define DOCKAUV_STR_(x) #x
+#define DOCKAUV_STR(x) DOCKAUV_STR_(x)
+    return "libdockauv gfx950 (HIP), abi " DOCKAUV_STR(DOCKAUV_ABI_VERSION) ", built " __DATE__ " " __TIME__;
 }
 
 const char* dockauv_last_error(dockauv_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
@@ -519,8 +521,21 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
         B.lane_cell = lc_dev;
     }
     {
-        void* st_dev = nullptr;   // sticky status word (dockauv_device.h: Buffers::status); dalloc zeroes it
-        ALLOC(st_dev, 256);
+        // sticky status word (dockauv_device.h: Buffers::status): host-coherent, mapped (see check_status)
+        void* st_host = nullptr;
+        void* st_dev = nullptr;
+        e = hipHostMalloc(&st_host, 256, hipHostMallocMapped | hipHostMallocCoherent);
+        if (e == hipSuccess) {
+            memset(st_host, 0, 256);
+            h->pinned_allocs.push_back(st_host);
+            e = hipHostGetDevicePointer(&st_dev, st_host, 0);
+        }
+        if (e != hipSuccess) {
+            fail(nullptr, DOCKAUV_E_HIP, "status word (mapped host memory): %s", hipGetErrorString(e));
+            dockauv_destroy(h);
+            return DOCKAUV_E_HIP;
+        }
+        h->status_host = static_cast<volatile unsigned int*>(st_host);
         B.status = static_cast<unsigned int*>(st_dev);
     }
     // host-pointer staging buffers
@@ -728,6 +743,18 @@ int dockauv_step_gather_sequence(dockauv_handle h, const dockauv_step_io* ios, i
     for (int i = 0; i < n; ++i)
         if (!ios[i].actions || !ios[i].obs || !ios[i].pack_reward_done)
             return fail(h, DOCKAUV_E_INVALID, "step %d: actions/obs must not be NULL and pack_reward_done must be set", i);
+    {
+        // the plans' slices are rows of the step's packed layout: float32 rows of n_obs + 2 words (pack_reward_done = 1)
+        const uint64_t row_bytes = (uint64_t)(h->n_obs + 2) * 4u * (uint64_t)h->cfg.n_envs;
+        for (int i = 0; i < n; ++i)
+            if (ios[i].pack_reward_done != 1)
+                return fail(h, DOCKAUV_E_INVALID, "step %d: the peer-to-peer gather ships float32 packed rows (pack_reward_done = 1); "
+                            "bfloat16 rows (2) are gathered over RCCL", i);
+        for (int k = 0; k < n_plans; ++k)
+            if (plans[k].bytes != row_bytes)
+                return fail(h, DOCKAUV_E_INVALID, "plan %d: slice of %llu bytes, the handle's packed rows are %llu", k,
+                            (unsigned long long)plans[k].bytes, (unsigned long long)row_bytes);
+    }
     HIP_TRY(h, hipSetDevice(h->device));
     hipStream_t cs = (hipStream_t)compute_stream, gs = (hipStream_t)gather_stream;
     const bool two = cs != gs;
@@ -849,8 +876,6 @@ int ensure_pinned(dockauv_handle h) {
     if ((rc = pinned_alloc(h, &h->pin.raydist, N * h->n_rays * t))) return rc;
     if ((rc = pinned_alloc(h, (void**)&h->pin.termobs, N * h->n_obs * 4))) return rc;
     if ((rc = pinned_alloc(h, &h->pin.statedot, N * 12 * t))) return rc;
-    if ((rc = pinned_alloc(h, (void**)&h->pin.status, 64))) return rc;
-    *h->pin.status = 0;
     HIP_TRY(h, hipStreamCreate(&h->host_stream));   // blocking stream: ordered after the null-stream copies of set_field / reset_envs
     h->pin.ready = true;
     return 0;
@@ -898,11 +923,8 @@ int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io) {
     if (io->nav) HIP_TRY(h, hipMemcpyAsync(h->pin.nav, h->d_nav, N * 4 * t, hipMemcpyDeviceToHost, s));
     if (io->ray_dist) HIP_TRY(h, hipMemcpyAsync(h->pin.raydist, h->d_raydist, N * h->n_rays * t, hipMemcpyDeviceToHost, s));
     if (io->state_dot) HIP_TRY(h, hipMemcpyAsync(h->pin.statedot, h->d_statedot, N * 12 * t, hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpyAsync(h->pin.status, h->f64 ? h->a64.B.status : h->a32.B.status, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
-    if (*h->pin.status != 0)
-        return fail(h, DOCKAUV_E_KERNEL, "step kernel status 0x%x: a tail role timed out waiting for its group's integrating wave; "
-                    "results are invalid, destroy the handle", *h->pin.status);
+    if ((rc = check_status(h)) != 0) return rc;
     if (io->terminal_obs) {
         // terminal observations only exist for envs that finished in this step: fetch the rows of those envs only
         // (typically none or a few; the buffer is as large as the observations themselves)
@@ -1044,6 +1066,11 @@ int dockauv_synchronize(dockauv_handle h) {
     HIP_TRY(h, hipSetDevice(h->device));
     if (h->last_stream) HIP_TRY(h, hipStreamSynchronize(h->last_stream)); else HIP_TRY(h, hipDeviceSynchronize());
     return check_status(h);
+}
+
+int dockauv_poll_status(dockauv_handle h) {
+    if (!h) return DOCKAUV_E_INVALID;
+    return check_status(h);   // (a plain load of host memory: no HIP call, no synchronisation)
 }
 
 int dockauv_time_steps(dockauv_handle h, const dockauv_step_io* io, void* hip_stream, int steps, double* avg_us) {

@@ -572,6 +572,12 @@ class BatchedDocking3d:
     def synchronize(self) -> None:
         _capi.check(self._lib, self._handle, self._lib.dockauv_synchronize(self._handle), "dockauv_synchronize")
 
+    def poll_status(self) -> None:
+        """Raise DockAUVError if a step kernel that has already run reported an internal time-out (the handle's sticky
+        status word, host-coherent memory): no synchronisation, a microsecond -- for rollouts on device pointers that
+        never call a synchronising entry point."""
+        _capi.check(self._lib, self._handle, self._lib.dockauv_poll_status(self._handle), "dockauv_poll_status")
+
     # ------------------------------------------------------------------------------------------ VecEnv odds and ends
     def close(self) -> None:
         if getattr(self, "_handle", None) is not None and self._handle.value:

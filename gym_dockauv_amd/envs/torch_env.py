@@ -67,6 +67,9 @@ class TorchDocking3d:
             term_ptr = self._terminal.data_ptr()
         self.batch.step_device(actions.data_ptr(), out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream,
                                packed=True, terminal_obs_ptr=term_ptr)
+        # the kernels' sticky status word (a tail role that gave up waiting: rows since are invalid) is host-coherent
+        # memory: looked at every step without a synchronisation; what it shows belongs to steps that have already run
+        self.batch.poll_status()
         return out[:, : self.n_obs], out[:, self.n_obs], out[:, self.n_obs + 1] > 0.5
 
     @property
@@ -74,7 +77,16 @@ class TorchDocking3d:
         return self._terminal
 
     def close(self) -> None:
+        """Raises DockAUVError (after releasing everything) if a step kernel of this env reported an internal time-out."""
+        err = None
+        try:
+            if getattr(self.batch, "_handle", None) is not None and self.batch._handle.value:
+                self.batch.synchronize()
+        except Exception as e:
+            err = e
         self.batch.close()
+        if err is not None:
+            raise err
 
 
 class ShardedTorchDocking3d:
@@ -225,6 +237,7 @@ class ShardedTorchDocking3d:
             raise ValueError(f"actions must be [{self.num_envs}, {self.n_u}] (global) or [{self.n_local}, {self.n_u}] (local)")
         buf = self.stepper.step(actions)
         self._steps += 1
+        self.batch.poll_status()   # (the step kernels' own status word: host-coherent, no synchronisation)
         if self._steps % self.check_every == 0:
             self._check_transport()
         if self.gather_dtype == "bf16":
@@ -236,6 +249,8 @@ class ShardedTorchDocking3d:
         err = None
         try:
             self._check_transport()
+            if getattr(self.batch, "_handle", None) is not None and self.batch._handle.value:
+                self.batch.synchronize()   # (reports the kernels' status word as well)
         except Exception as e:          # still release everything; re-raise afterwards
             err = e
         if hasattr(self.stepper, "close"):

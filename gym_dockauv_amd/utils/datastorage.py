@@ -254,11 +254,11 @@ class BatchEpisodeStorage:
                         self._closed[env_id] = True
         return written
 
-    def on_reset(self, env_ids, save_partial: bool = False):
+    def on_reset(self, env_ids, save_partial: bool = True):
         """Host-side reset of `env_ids` (BatchedDocking3d.reset / reset_envs): the steps recorded so far are pulled from
-        the ring first; a selected env's running (unfinished) episode is dropped -- or written with save_partial, as the
-        reference saves its storage inside reset() (envs/docking3d.py:252-256) -- so that its rows never join the next
-        episode's."""
+        the ring first; a selected env's running (unfinished) episode is WRITTEN, as the reference saves its storage
+        inside reset() (envs/docking3d.py:252-256: update + save before anything is reset) -- save_partial=False drops
+        it instead -- so that its rows never join the next episode's."""
         written = self.flush()
         for env_id in np.intersect1d(np.asarray(env_ids, dtype=np.int64), self.ids).tolist():
             if self._open[env_id]:

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DOCKAUV_ABI_VERSION 2
+#define DOCKAUV_ABI_VERSION 3
 #define DOCKAUV_MAX_U 8          /* inputs: BlueROV2 joystick 6, BlueROV2 direct 8, LAUV 3 */
 #define DOCKAUV_N_REWARDS 13     /* envs/docking3d.py:152 */
 #define DOCKAUV_N_CONDITIONS 5   /* envs/docking3d.py:597-619 */
@@ -42,7 +42,8 @@ extern "C" {
 #define DOCKAUV_E_KERNEL (-5)    /* a step kernel reported an internal time-out in the handle's sticky status word (an
                                     intra-group wait gave up instead of hanging the GPU); reported by the calls that
                                     synchronise: dockauv_synchronize, dockauv_get_field, dockauv_step_host,
-                                    dockauv_time_steps, dockauv_trace_read.  Results since are invalid. */
+                                    dockauv_time_steps, dockauv_trace_read -- and by dockauv_poll_status, which does
+                                    not.  Results since are invalid. */
 
 /* device arithmetic type of the path */
 #define DOCKAUV_F32 0            /* product path ("within 1e-5 of the float64 reference") */
@@ -220,6 +221,11 @@ int dockauv_step_sequence(dockauv_handle h, const dockauv_step_io* ios, int n, v
 int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io);
 /* block until everything queued on the handle's last-used stream is done */
 int dockauv_synchronize(dockauv_handle h);
+/* the handle's sticky kernel status WITHOUT any synchronisation (the word lives in host-coherent memory): 0, or
+ * DOCKAUV_E_KERNEL once a step kernel that has already run gave up an internal wait.  For device-resident rollouts that
+ * never call a synchronising entry point (the reference has no counterpart: its step() raises in the caller's thread);
+ * cheap enough for every step. */
+int dockauv_poll_status(dockauv_handle h);
 
 /*
  * Episode storage for selected envs of a batch (utils/datastorage.py:164-343 EpisodeDataStorage, hooked at

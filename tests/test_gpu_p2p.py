@@ -156,6 +156,39 @@ def test_sequence_argument_checks():
     env.close()
 
 
+def test_riding_gather_of_sensor_free_handles_beyond_65536_envs():
+    """sensor-free handles beyond 65 536 envs run the 128- / 64-thread kernels, whose default instantiation has
+    write-back stores and carries no copy groups; a lag-1 sequence must get the write-through one (every step of the
+    sequence launches, the riding gathers deliver the rows bit for bit) -- and bfloat16 rows are refused up front."""
+    import torch
+    from gym_dockauv_amd import _capi
+    from gym_dockauv_amd.envs.batched import BASE_CONFIG, BatchedDocking3d
+    from gym_dockauv_amd.parallel import P2PShardedStepper
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    for n in (65536 + 64, 131072 + 64):          # 128 threads per group, 64 threads per group
+        env = BatchedDocking3d(BASE_CONFIG, num_envs=n, scenario="SimpleDocking3d", device=0, precision="f32",
+                               reset_mode="device", device_seed=3, rng="batched")
+        env.reset()
+        st = P2PShardedStepper(n, env.n_observations + 2, lambda a, o: None, dev, world=1, rank=0)
+        actions = torch.rand((n, env.n_u), device=dev) * 2 - 1
+        ios = (_capi.StepIO * 4)()
+        for i in range(4):
+            ios[i].actions, ios[i].obs, ios[i].pack_reward_done = actions.data_ptr(), st.rows2[i & 1].data_ptr(), 1
+        lib, g = st.gather.lib, st.gather
+        rc = lib.dockauv_step_gather_sequence(env._handle, ios, 4, g._plans, 4, 0, 1, stream, stream)
+        assert rc == 0, lib.dockauv_last_error(env._handle)
+        torch.cuda.synchronize()
+        assert torch.equal(st.bufs[3], st.rows2[1]) and torch.equal(st.bufs[2], st.rows2[0])
+        assert bool(torch.isfinite(st.rows2[1]).all()) and float(st.rows2[1].abs().max()) > 0 and g.timed_out() == 0
+        for i in range(4):
+            ios[i].pack_reward_done = 2
+        assert lib.dockauv_step_gather_sequence(env._handle, ios, 4, g._plans, 4, 4, 1, stream, stream) == -1
+        assert b"float32 packed rows" in lib.dockauv_last_error(env._handle)
+        st.close()
+        env.close()
+
+
 def test_sharded_env_single_rank_equals_torch_env():
     """ShardedTorchDocking3d with one rank (both transports) hands out what TorchDocking3d does, bit for bit."""
     import numpy as np

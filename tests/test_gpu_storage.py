@@ -129,7 +129,8 @@ def test_state_dot_output_matches_oracle(precision):
 
 
 def test_storage_across_host_resets_and_after_done(tmp_path):
-    """(a) a mid-episode host reset must not join the abandoned rows to the next episode; (b) with
+    """(a) a mid-episode host reset must not join the abandoned rows to the next episode -- they are saved as an
+    episode of their own, like the reference does; (b) with
     reset_mode "none" a finished env that is stepped on reports its conditions every step -- ONE pickle, not one per step."""
     name = "traj_ObstaclesCurrentDocking3d_bluerov2_random"
     g = H.load(name)
@@ -145,7 +146,12 @@ def test_storage_across_host_resets_and_after_done(tmp_path):
             a[sel, :n_u] = g["action"][t]
             env.step(a)
         env.reset_envs(sel, H.episode_arrays(g, [1] * len(sel), max_caps, max_sph))   # ... abandoned by a host reset
-        assert store.files == []
+        # the abandoned episodes are written as they stand, as the reference's reset() saves its storage before it resets
+        # (envs/docking3d.py:252-256): ten steps each, no terminal condition
+        assert len(store.files) == len(sel)
+        for f in store.files:
+            part = pickle.load(open(f, "rb"))
+            assert part["vehicle"]["states"].shape[0] == 11 and part["conditions_last_step"] == 0
         first_done = None
         for t in range(int(g["meta_max_timesteps"]) + 8):     # episode 1 to its time limit, then stepped on 7 more times
             a[sel, :n_u] = g["action"][(int(g["ep_start"][1]) + t) % int(g["meta_T"])]
@@ -154,8 +160,8 @@ def test_storage_across_host_resets_and_after_done(tmp_path):
                 first_done = t
         store.flush()
         assert first_done is not None
-        assert len(store.files) == len(sel), store.files      # one pickle per selected env
-        st = pickle.load(open(store.files[0], "rb"))
+        assert len(store.files) == 2 * len(sel), store.files  # + one pickle per selected env
+        st = pickle.load(open(store.files[len(sel)], "rb"))
         assert st["vehicle"]["states"].shape[0] == first_done + 2          # reset row + its own steps only
         np.testing.assert_allclose(st["vehicle"]["states"][0, 0:3], g["ep_position"][1], atol=1e-9)
         assert st["conditions_last_step"] != 0
