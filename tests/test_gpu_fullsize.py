@@ -93,6 +93,13 @@ def test_config3_full_size(name):
     run_tiled([name], 65536)
 
 
+def test_config3_write_back_twin_beyond_262144_envs():
+    """The 256-thread ray kernel has a twin with write-back stores that launch_vk (dockauv_step.hip.inc) only picks for
+    batches beyond 262 144 envs -- launches that run in several rounds of groups.  Same source, other stores: here it meets
+    the reference's rows like every other product kernel (262 208 envs = 4 097 groups, the smallest batch that selects it)."""
+    run_tiled(["traj_SphereDocking3d_bluerov2_fan16_random"], 262144 + 64)
+
+
 # "_near": vehicles that start 4-6 m from a capsule and face it -- 30-50 % of all rays in range, every step with hits
 # (oracle/gen_golden.py: gen_near_obstacles); the older LAUV trajectories never have a ray in range (min_ray = 10.0)
 MIXED_PAIRS = {
