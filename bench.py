@@ -179,6 +179,9 @@ def make_env(wl, local_rank: int, rank: int, threads: int):
                            threads_per_group=threads)
     env._gen = np.random.default_rng(1000 + rank)
     env.reset()
+    # `value` and every per-launch figure: one launch per step (what a policy in the loop gets); the resident fast path of
+    # dockauv_step_sequence is measured on its own (`sequence_resident`)
+    env.set_sequence_resident(False)
     if wl["current_speed"] == "uniform01":
         # per-env current speed U(0, 1) (the scenario itself fixes 0.5 m/s, docking3d.py:985);
         # V_min = V_max = V_c as in SimpleCurrentDocking3d (docking3d.py:844-848).  Episodes generated in-kernel after
@@ -267,6 +270,25 @@ def timed_regions(run, steps, warmup_steps, warm_i0, min_seconds, max_reps, sync
 KERNEL_TIMING = ("HIP events recorded on the launch stream around each timed region of K launches queued back to back by one "
                  "dockauv_step_sequence call: median region time / K = the average launch duration, launch boundary included "
                  "(an upper bound of the kernel's own duration; rocprofv3's queued dispatches report the same quantity)")
+
+
+def resident_sequence_rate(env, run, args, torch, config_id, N, per_launch_us):
+    """The same timed regions with dockauv_step_sequence's RESIDENT fast path: launches of up to 64 steps in which every
+    64-env group walks its envs through all of them -- no launch boundary between steps (include/dockauv.h).  Open-loop
+    sequences only; reported beside the per-launch `value`, never instead of it."""
+    env.set_sequence_resident(True)
+    ev_ms = []
+    times = timed_regions(run, args.steps, min(args.warmup, 128), 0, args.min_seconds / 2, args.max_reps, torch.cuda.synchronize,
+                          lambda: None, lambda x: x, event_ms=ev_ms, torch=torch)
+    env.set_sequence_resident(False)
+    med = statistics.median(times)
+    us = statistics.median(ev_ms) / args.steps * 1e3
+    gbps = ALGO_BYTES[config_id] * N / (us * 1e-6) / 1e9
+    return {"value": N * args.steps / med, "unit": "env-steps/s", "ms_per_step": med / args.steps * 1e3, "us_per_step_events": us,
+            "reps": len(times), "steps_per_launch": 64, "achieved_GBps_algorithmic": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS,
+            "vs_per_launch": us / per_launch_us if per_launch_us else None,
+            "what": "dockauv_step_sequence with its resident fast path: K steps as ceil(K / 64) launches, each group walking its 64 "
+                    "envs through the launch's steps (state through L2 between steps, rows and actions as in K launches: same bytes)"}
 
 
 def isolated_kernel_us(env, actions, out, ring, stream, torch, launches):
@@ -366,6 +388,7 @@ def measure_ray_dense(config_id, args, torch, dev, local_rank, rank, ksha):
                            reset_mode="none", rng="batched", vehicles=wl["vehicles"], threads_per_group=args.threads)
     env._gen = np.random.default_rng(2000 + rank)
     env.reset()
+    env.set_sequence_resident(False)   # (per-launch figures, as everywhere in this line but `sequence_resident`)
     rng = np.random.default_rng(3000 + rank)
     n_obs, n_u = env.n_observations, env.n_u
     hold = torch.zeros((N, n_u), device=dev, dtype=torch.float32)
@@ -447,10 +470,11 @@ def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, ke
     if args.steps < 100:
         kernel_us = iso
     cl = None if args.no_closed_loop else closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400)
+    resident = None if args.no_resident else resident_sequence_rate(env, run, args, torch, config_id, N, kernel_us)
     res = {"workload": wl["name"], "envs": N, "value": N * args.steps / med, "unit": "env-steps/s",
            "ms_per_step": med / args.steps * 1e3, "reps": len(times), "kernel_us": kernel_us,
            "roofline": roofline_of(config_id, N, kernel_us, len(ev_ms) * args.steps, ksha, variant="sorted" if layout == "vehicle_sorted" else ""),
-           "closed_loop": cl, "obs_finite": finite}
+           "closed_loop": cl, "sequence_resident": resident, "obs_finite": finite}
     if iso is not None:
         res["kernel_us_isolated_launches"] = iso
     env.close()
@@ -532,6 +556,7 @@ def main():
     ap.add_argument("--no-closed-loop", action="store_true",
                     help="skip the closed-loop sub-measurement (its launches are issued from Python one by one: profiling runs "
                          "use this so that rocprofv3's per-kernel average covers the queued launches of the timed regions only)")
+    ap.add_argument("--no-resident", action="store_true", help="skip the sequence_resident sub-measurement")
     ap.add_argument("--isolated-kernel-timing", action="store_true",
                     help="also report kernel_us_isolated_launches: per-dispatch events on launches issued one by one")
     ap.add_argument("--only-ray-dense", type=int, default=0, metavar="CONFIG",
@@ -808,6 +833,8 @@ def main():
         finite = bool(torch.isfinite(last).all().item())
         n_done = int((out_l[:, n_obs + 1] > 0.5).sum().item())
     closed = closed_loop_rate(env, torch, dev, N, n_obs, n_u, 400) if world == 1 and not use_dist and not args.no_closed_loop else None
+    resident = (resident_sequence_rate(env, run, args, torch, config_id, N, kernel_us)
+                if world == 1 and not use_dist and not args.no_resident and args.steps >= 2 else None)
 
     sweep = []
     if world == 1 and not args.no_sweep and not args.envs:
@@ -819,6 +846,7 @@ def main():
                                   vehicles=(wl["vehicles"] * (n_big // N + 1))[:n_big] if wl["vehicles"] else None)
             e2._gen = np.random.default_rng(7)
             e2.reset()
+            e2.set_sequence_resident(False)
             a2 = torch.rand((4, n_big, n_u), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
             o2 = torch.zeros((n_big, n_obs + 2), device=dev, dtype=torch.float32)
             seq2 = e2.make_step_sequence([a2[r % 4].data_ptr() for r in range(20)], [o2.data_ptr()] * 20, packed=True)
@@ -901,6 +929,8 @@ def main():
             out["kernel_us_isolated_launches"] = kernel_us_iso
         if closed:
             out["closed_loop"] = closed
+        if resident:
+            out["sequence_resident"] = resident
         if alone:
             out["same_workload_without_gather"] = alone
         if bf16_gather:
@@ -925,7 +955,7 @@ def main():
                 if cid == config_id:
                     subs.append({"workload": wl["name"], "envs": N, "value": out["value"], "unit": "env-steps/s",
                                  "ms_per_step": out["ms_per_step"], "reps": len(times), "kernel_us": kernel_us,
-                                 "roofline": out["roofline"], "closed_loop": closed, "headline": True})
+                                 "roofline": out["roofline"], "closed_loop": closed, "sequence_resident": resident, "headline": True})
                 else:
                     subs.append(measure_single(cid, 0, args, torch, dev, local_rank, rank, ksha))
                 if cid == 5:     # both layouts of the mixed batch

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdockauv.so")
 
 ABI_VERSION = 3
+OPT_SEQUENCE_RESIDENT = 1
 MAX_U = 8
 N_REWARDS = 13
 N_CONDITIONS = 5
@@ -108,6 +109,7 @@ SYMBOLS = [
     ("dockauv_reset_envs", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("dockauv_step", C.c_int, [C.c_void_p, C.POINTER(StepIO), C.c_void_p]),
     ("dockauv_step_sequence", C.c_int, [C.c_void_p, C.POINTER(StepIO), C.c_int, C.c_void_p]),
+    ("dockauv_set_option", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("dockauv_step_host", C.c_int, [C.c_void_p, C.POINTER(StepIO)]),
     ("dockauv_synchronize", C.c_int, [C.c_void_p]),
     ("dockauv_poll_status", C.c_int, [C.c_void_p]),

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_DIR = os.path.join(os.path.dirname(HERE), "lib")
 OUT = os.path.join(LIB_DIR, os.environ.get("DOCKAUV_LIB_NAME", "libdockauv.so"))
-SOURCES = ["dockauv_kernels_f32.hip", "dockauv_kernels_f64.hip", "dockauv_capi.hip", "dockauv_p2p.hip"]
+SOURCES = ["dockauv_kernels_f32.hip", "dockauv_kernels_f64.hip", "dockauv_kernels_seq.hip", "dockauv_capi.hip", "dockauv_p2p.hip"]
 DEPS = SOURCES + ["dockauv_step.hip.inc", "dockauv_device.h", "dockauv_ride.h", os.path.join("..", "..", "include", "dockauv.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: the SLP vectoriser packs independent f32 ops into v_pk_* pairs; on this kernel that costs ~370

@@ -46,6 +46,7 @@ struct dockauv_env_s {
     KernelArgs<float, 2> a32{};
     KernelArgs<double, 2> a64{};
     std::string err;
+    bool seq_resident = true;   // dockauv_set_option(DOCKAUV_OPT_SEQUENCE_RESIDENT)
     volatile unsigned int* status_host = nullptr;   // the kernels' sticky status word: pinned, host-coherent, mapped into the device
     hipStream_t last_stream = nullptr;
     // host-pointer step staging
@@ -426,11 +427,17 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
     if (c.threads_per_group > 0) h->threads = c.threads_per_group;
     else if (!h->has_rays) h->threads = c.n_envs <= 65536 ? 256 : (c.n_envs <= 131072 ? 128 : 64);
     else {
-        // (light fans -- config 3's 16 beams x 8 spheres -- beyond ~8 rounds of resident groups: one wave per group does
-        // the least total work there as well: 1 048 576 envs 171.5 -> 143.6 us, 524 288 envs 68.6 -> 66.8; heavy fans
-        // stay at four waves: config 4 at 1 048 576 envs 250 us against 319; scripts/diag/threads_large.sh)
+        // Beyond the batch sizes at which every group is resident at once, ONE wave per group does the least total work and
+        // -- since round 4, when its LDS footprint was halved (dockauv_step.hip.inc: SOLO; 16 instead of 8 groups per CU for
+        // config 3's fan) -- keeps the most groups in flight.  Same-box measurements (profiles/r4/threads_large.txt), light
+        // fan (config 3, 16 beams x 8 spheres) 64 against 256 threads: 131 072 envs 18.4 / 16.7 us, 196 608: 23.0 / 26.0,
+        // 262 144: 27.0 / 34.3, 524 288: 50.9 / 69.3, 1 048 576: 117.9 / 175.7; heavy fan (config 4, 63 rays x 5 capsules):
+        // 524 288: 115.6 / 113.7, 1 048 576: 236 / 251; mixed vehicles (config 5): 256 threads at every size (229 / 251 at 1 M).
         const long tests = (long)h->n_rays * (c.max_capsules + c.max_spheres);
-        h->threads = (tests >= 256 && c.n_envs <= 32768) ? 512 : ((tests < 256 && c.n_envs > 524288) ? 64 : 256);
+        const bool light = tests < 256;
+        if (!light && c.n_envs <= 32768) h->threads = 512;
+        else if (light ? c.n_envs > 163840 : (c.n_vehicles == 1 && c.n_envs > 786432)) h->threads = 64;
+        else h->threads = 256;
     }
     if (c.n_vehicles == 2) {
         if (!(c.vehicle[0].kind == DOCKAUV_VEH_CONSTB && b_is_diagonal(c.vehicle[0]) && c.vehicle[1].kind == DOCKAUV_VEH_LAUV)) {
@@ -722,6 +729,33 @@ int dockauv_step(dockauv_handle h, const dockauv_step_io* io, void* hip_stream) 
     return launch(h, io, (hipStream_t)hip_stream);
 }
 
+namespace {
+// Can the steps ios[0..n) run as ONE resident launch (dockauv_step.hip.inc: step_seq_kernel)?  What the plain float32 product
+// kernels of the structural fast path serve, with packed rows of one kind: everything else is launched step by step.
+bool sequence_is_resident_material(dockauv_handle h, const dockauv_step_io* ios, int n) {
+    if (!h->seq_resident || n < 2 || h->f64 || !h->sym || h->vk == VK_DENSEB) return false;
+    int pl = 0;
+    while ((1 << pl) < h->n_rays) ++pl;
+    const bool odd_fan = h->has_rays && !(pl == 6 || pl == 4);
+    if (h->cfg.reset_mode == DOCKAUV_RESET_POOL || h->cfg.reward_set == 2 || odd_fan || h->trace_dev || h->cfg.device_noise) return false;
+    for (int i = 0; i < n; ++i) {
+        if (ios[i].noise || ios[i].reward_terms || ios[i].conditions || ios[i].nav || ios[i].ray_dist || ios[i].terminal_obs ||
+            ios[i].state_dot || ios[i].reward || ios[i].done)
+            return false;
+        if (ios[i].pack_reward_done == 0 || ios[i].pack_reward_done != ios[0].pack_reward_done) return false;
+    }
+    return true;
+}
+}  // namespace
+
+int dockauv_set_option(dockauv_handle h, int option, int value) {
+    if (!h) return DOCKAUV_E_INVALID;
+    switch (option) {
+        case DOCKAUV_OPT_SEQUENCE_RESIDENT: h->seq_resident = value != 0; return 0;
+    }
+    return fail(h, DOCKAUV_E_INVALID, "unknown option %d", option);
+}
+
 int dockauv_step_sequence(dockauv_handle h, const dockauv_step_io* ios, int n, void* hip_stream) {
     if (!h || !ios || n < 0) return fail(h, DOCKAUV_E_INVALID, "bad argument");
     for (int i = 0; i < n; ++i) {
@@ -730,6 +764,31 @@ int dockauv_step_sequence(dockauv_handle h, const dockauv_step_io* ios, int n, v
             return fail(h, DOCKAUV_E_INVALID, "step %d: reward/done must not be NULL unless pack_reward_done", i);
     }
     HIP_TRY(h, hipSetDevice(h->device));
+    if (sequence_is_resident_material(h, ios, n)) {
+        // the fast path: chunks of up to kSeqMax steps, each ONE launch in which every group walks its envs through the
+        // chunk's steps (no launch boundary between them); same bytes as the loop below writes
+        set_io(h->a32.io, ios[0]);
+        h->a32.io.trace = nullptr;
+        h->a32.io.trace_step = 0;
+        h->a32.io.device_noise = 0;
+        bool fell_back = false;
+        for (int i0 = 0; i0 < n && !fell_back; i0 += kSeqMax) {
+            SeqArgs seq;
+            seq.n = std::min(kSeqMax, n - i0);
+            for (int k = 0; k < kSeqMax; ++k) {
+                const int i = i0 + std::min(k, seq.n - 1);
+                seq.actions[k] = ios[i].actions;
+                seq.obs[k] = ios[i].obs;
+            }
+            const int rc = launch_sequence_f32(h->a32, h->vk, h->sym, h->has_rays, h->threads, seq, (hipStream_t)hip_stream);
+            if (rc == (int)hipErrorNotSupported && i0 == 0) { fell_back = true; break; }
+            if (rc != 0) return fail(h, DOCKAUV_E_HIP, "resident step sequence launch failed: %s", hipGetErrorString((hipError_t)rc));
+        }
+        if (!fell_back) {
+            h->last_stream = (hipStream_t)hip_stream;
+            return 0;
+        }
+    }
     for (int i = 0; i < n; ++i) {
         int rc = launch(h, &ios[i], (hipStream_t)hip_stream);
         if (rc) return rc;

@@ -155,6 +155,15 @@ struct RideLaunch {
     int groups = 0;               // copy groups appended to the grid
 };
 
+// Resident step sequence (dockauv_step_sequence's fast path, dockauv_step.hip.inc: step_seq_kernel): the action / row
+// pointers of up to kSeqMax consecutive steps travel in the kernarg segment of ONE launch.
+constexpr int kSeqMax = 64;
+struct SeqArgs {
+    const void* actions[kSeqMax];
+    float* obs[kSeqMax];
+    int n;
+};
+
 // host-side bundle of everything a launch needs
 template <typename T, int NV>
 struct KernelArgs {
@@ -184,6 +193,16 @@ constexpr int kHxFields = 21;    // env phase -> tail waves: state (12), V_c, ac
 
 template <typename T>
 inline size_t lds_bytes(int epg, int nt, int max_cap, int max_sph, int n_obs, bool rays) {
+    if (rays && nt / epg == 1) {
+        // one-wave ray groups (dockauv_step.hip.inc: SOLO): no pose rows (registers); the observation tile overlays the
+        // obstacle records; behind the larger of the two: obstacle-avoidance sums (2 rows), the list of active envs (1 row),
+        // and the ray cells [epg][n_red] the passes accumulate
+        const size_t rec = (size_t)epg * (kCapFields * max_cap + kSphFields * max_sph) * sizeof(T);
+        const size_t tile = (size_t)epg * (n_obs + 2) * sizeof(float);
+        size_t bytes = ((rec > tile ? rec : tile) + 15) & ~(size_t)15;
+        bytes = (bytes + (size_t)epg * 3 * sizeof(T) + 15) & ~(size_t)15;
+        return bytes + (size_t)epg * (n_obs - 16) * sizeof(float);
+    }
     size_t t_elems = rays ? (size_t)epg * (kPoseFields + kCapFields * max_cap + kSphFields * max_sph + 4 * (nt / epg)) : 0;
     if (nt / epg >= 2) t_elems += (size_t)epg * (kHxFields + kSpecFields);
     size_t bytes = t_elems * sizeof(T);
@@ -198,6 +217,11 @@ int launch_step_f32(const KernelArgs<float, 2>& a, int vk, bool sym, bool has_ra
                     void* ev0 = nullptr, void* ev1 = nullptr);
 int launch_step_f64(const KernelArgs<double, 2>& a, int vk, bool sym, bool has_rays, int threads, void* stream,
                     void* ev0 = nullptr, void* ev1 = nullptr);
+
+// n <= kSeqMax steps of the handle in ONE launch (every group walks its 64 envs through all of them): float32 product
+// kernels of the structural fast path only (dockauv_kernels_seq.hip); hipErrorNotSupported = the caller launches the steps
+// one by one.  a.io: everything but actions / obs, which come from `seq`.
+int launch_sequence_f32(const KernelArgs<float, 2>& a, int vk, bool sym, bool has_rays, int threads, const SeqArgs& seq, void* stream);
 
 #ifdef DOCKAUV_STAMPS
 int read_stamps(unsigned long long* out);   // diagnostic build only

@@ -552,9 +552,15 @@ class BatchedDocking3d:
         return ios
 
     def run_step_sequence(self, ios, stream: int = 0) -> None:
-        """Queue every step of a prepared sequence back-to-back on `stream` (asynchronous, one host call)."""
+        """Queue every step of a prepared sequence on `stream` (asynchronous, one host call): as resident launches of up to
+        64 steps each where the product kernels serve them (include/dockauv.h: dockauv_step_sequence), else back to back."""
         rc = self._lib.dockauv_step_sequence(self._handle, ios, len(ios), C.c_void_p(stream or None))
         _capi.check(self._lib, self._handle, rc, "dockauv_step_sequence")
+
+    def set_sequence_resident(self, on: bool) -> None:
+        """Switch the resident fast path of run_step_sequence (on by default) for this handle."""
+        rc = self._lib.dockauv_set_option(self._handle, _capi.OPT_SEQUENCE_RESIDENT, 1 if on else 0)
+        _capi.check(self._lib, self._handle, rc, "dockauv_set_option")
 
     def time_steps_device(self, actions_ptr: int, obs_ptr: int, reward_ptr: int = 0, done_ptr: int = 0, steps: int = 1,
                           stream: int = 0, packed: bool = False, terminal_obs_ptr: int = 0) -> float:

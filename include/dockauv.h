@@ -217,6 +217,15 @@ int dockauv_step(dockauv_handle h, const dockauv_step_io* io, void* hip_stream);
  * an open-loop action sequence (the manual / scripted loops of train.py:108-117, 238) without a host round trip per
  * step.  Equivalent to n calls of dockauv_step. */
 int dockauv_step_sequence(dockauv_handle h, const dockauv_step_io* ios, int n, void* hip_stream);
+/* Fast path of dockauv_step_sequence (ABI 3): when the steps are what the float32 product kernels serve (mandatory outputs as
+ * packed rows of one kind, reset mode NONE / DEVICE, reward set 1, fans of 9-16 or 33-64 rays, no logging) they run as
+ * RESIDENT launches of up to 64 steps each -- every 64-env group walks its envs through all steps of the launch, step k
+ * reading ios[k].actions and writing ios[k].obs, with no launch boundary in between.  The bytes written are exactly those of
+ * n single launches (tests/test_gpu_reset.py); what differs is WHEN: rows of different groups belong to different steps
+ * while the call is in flight, so the buffers must not be consumed before the call has completed on the stream (an
+ * open-loop sequence; a policy in the loop uses dockauv_step).  On by default; dockauv_set_option switches it per handle. */
+#define DOCKAUV_OPT_SEQUENCE_RESIDENT 1   /* value 0: dockauv_step_sequence launches its steps one by one */
+int dockauv_set_option(dockauv_handle h, int option, int value);
 /* same with host pointers (staged through the library's pinned buffers; synchronous) */
 int dockauv_step_host(dockauv_handle h, const dockauv_step_io* io);
 /* block until everything queued on the handle's last-used stream is done */

@@ -95,9 +95,22 @@ def test_config3_full_size(name):
 
 def test_config3_write_back_twin_beyond_262144_envs():
     """The 256-thread ray kernel has a twin with write-back stores that launch_vk (dockauv_step.hip.inc) only picks for
-    batches beyond 262 144 envs -- launches that run in several rounds of groups.  Same source, other stores: here it meets
+    batches beyond 262 144 envs -- launches that run in several rounds of groups (heavy fans, or a caller's choice of 256
+    threads: light fans get one wave per group there).  Same source, other stores: here it meets
     the reference's rows like every other product kernel (262 208 envs = 4 097 groups, the smallest batch that selects it)."""
-    run_tiled(["traj_SphereDocking3d_bluerov2_fan16_random"], 262144 + 64)
+    run_tiled(["traj_SphereDocking3d_bluerov2_fan16_random"], 262144 + 64, threads=256)   # (0 = auto: one wave per group there)
+
+
+@pytest.mark.parametrize("which,precision", [("sphere", "f32"), ("sphere", "f64"), ("lauv_near", "f32"), ("lauv_ram", "f32"),
+                                             ("mixed_near", "f32"), ("mixed_near", "f64")])
+def test_one_wave_ray_groups_vs_reference(which, precision):
+    """Ray groups of ONE wave (threads_per_group = 64: what dockauv_create picks for light fans beyond 524 288 envs) keep
+    pose, slot counts, masks and the collision flag in registers and overlay the observation tile on the obstacle records
+    (dockauv_step.hip.inc: SOLO) -- a layout of their own, held to the reference's rows here: 16-lane and 64-lane fans,
+    spheres and capsules (with collisions), the mixed kernel, both precisions; batch not a multiple of 64."""
+    names = {"sphere": ["traj_SphereDocking3d_bluerov2_fan16_random"], "lauv_near": ["traj_ObstaclesDocking3d_lauv_near"],
+             "lauv_ram": ["traj_ObstaclesDocking3d_lauv_ram"], "mixed_near": MIXED_PAIRS["near"]}[which]
+    run_tiled(names, 1000, precision, threads=64)
 
 
 # "_near": vehicles that start 4-6 m from a capsule and face it -- 30-50 % of all rays in range, every step with hits

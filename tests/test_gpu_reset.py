@@ -121,35 +121,71 @@ def test_tail_group_and_large_batch():
         big.close()
 
 
+SEQ_CASES = {
+    # name: (bench config id or scenario kwargs, envs, threads)
+    "config2_256": (2, 777, 0), "config2_128": (2, 1000, 128), "config2_64": (2, 1000, 64),
+    "config3_256": (3, 777, 0), "config3_64": (3, 1000, 64),
+    "config4_512": (4, 777, 512), "config4_256": (4, 777, 256),
+    "config5_256": (5, 778, 0), "config5_64": (5, 778, 64),
+}
+
+
 @pytest.mark.gpu
-def test_step_sequence_equals_single_steps():
-    """dockauv_step_sequence(n) == n x dockauv_step on the same inputs, bit for bit (same kernel, same order)."""
+@pytest.mark.parametrize("case", sorted(SEQ_CASES))
+def test_step_sequence_equals_single_steps(case):
+    """dockauv_step_sequence(n) == n x dockauv_step on the same inputs, bit for bit -- as launches queued back to back
+    (option off) AND as the resident fast path (default: every group walks its envs through up to 64 steps per launch, no
+    launch boundary in between; include/dockauv.h).  70 steps = two resident launches; episodes are short, so in-kernel
+    resets happen inside the sequences; every BASELINE workload's kernel, every group shape; packed float32 and bfloat16
+    rows; distinct output rows per step and one buffer for all steps (then the last step's rows must be what is left)."""
+    import copy
+    import sys
+    import os
     import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     from gym_dockauv_amd.envs.batched import BatchedDocking3d
-    N, K = 777, 6
+    cid, N, threads = SEQ_CASES[case]
+    K = 70
     dev = torch.device("cuda", 0)
-    outs = []
-    for mode in ("single", "sequence"):
-        env = BatchedDocking3d(num_envs=N, scenario="ObstaclesCurrentDocking3d", precision="f32", reset_mode="device",
-                               device_seed=99, rng="batched")
+    wl = bench.workload(cid, N)
+    cfg = copy.deepcopy(wl["cfg"])
+    cfg["max_timesteps"] = 23
+    outs = {}
+    for mode in ("single", "launches", "resident", "resident_one_buffer", "resident_bf16", "single_bf16"):
+        env = BatchedDocking3d(cfg, num_envs=N, scenario=wl["scenario"], precision="f32", reset_mode="device", device_seed=99,
+                               rng="batched", vehicles=wl["vehicles"], threads_per_group=threads)
         env._gen = np.random.default_rng(3)
         env.reset()
         g = torch.Generator(device=dev)
         g.manual_seed(5)
         acts = torch.rand((K, N, env.n_u), device=dev, generator=g) * 2 - 1
-        out = torch.zeros((K, N, env.n_observations + 2), device=dev)
+        packed = "bf16" if mode.endswith("bf16") else True
+        words = env.packed_row_words(packed)
+        out = torch.zeros((K, N, words), device=dev, dtype=torch.float32)
         stream = torch.cuda.current_stream().cuda_stream
-        if mode == "single":
+        if mode.startswith("single"):
             for k in range(K):
-                env.step_device(acts[k].data_ptr(), out[k].data_ptr(), stream=stream, packed=True)
+                env.step_device(acts[k].data_ptr(), out[k].data_ptr(), stream=stream, packed=packed)
         else:
-            ios = env.make_step_sequence([acts[k].data_ptr() for k in range(K)], [out[k].data_ptr() for k in range(K)])
+            env.set_sequence_resident(mode.startswith("resident"))
+            one = mode == "resident_one_buffer"
+            ios = env.make_step_sequence([acts[k].data_ptr() for k in range(K)],
+                                         [out[0 if one else k].data_ptr() for k in range(K)], packed=packed)
             env.run_step_sequence(ios, stream=stream)
         torch.cuda.synchronize()
-        outs.append((out.cpu().numpy(), env.state.copy()))
+        env.synchronize()
+        outs[mode] = (out.cpu().numpy().view(np.uint32), env.state.copy(), env.get_field(9).copy(), env.t_steps.copy())
         env.close()
-    assert np.array_equal(outs[0][0], outs[1][0], equal_nan=True)
-    assert np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
+    ref = outs["single"]
+    assert int(ref[2].max()) >= 2, "episodes must end inside the sequence"       # (episode counters: resets happened)
+    for mode in ("launches", "resident"):
+        for a, b in zip(ref, outs[mode]):
+            assert np.array_equal(a, b), f"{case}: {mode} differs from single launches"
+    one = outs["resident_one_buffer"]
+    assert np.array_equal(one[0][0], ref[0][K - 1]) and all(np.array_equal(a, b) for a, b in zip(ref[1:], one[1:]))
+    for a, b in zip(outs["single_bf16"], outs["resident_bf16"]):
+        assert np.array_equal(a, b), f"{case}: resident bf16 rows differ from single launches"
 
 
 @pytest.mark.gpu
