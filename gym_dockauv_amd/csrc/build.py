@@ -12,8 +12,12 @@ DEPS = SOURCES + ["dockauv_step.hip.inc", "dockauv_device.h", "dockauv_ride.h", 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: the SLP vectoriser packs independent f32 ops into v_pk_* pairs; on this kernel that costs ~370
 # v_mov to build the aligned register pairs and pushes the step kernel from 113 to ~200 VGPRs (4 -> 2 waves/SIMD)
+# -ffp-contract=on: a multiply-add is fused where the SOURCE writes it inside one expression, and nowhere else.  hipcc's default
+# ("fast": the backend fuses whatever it finds after inlining and CSE) gave two instantiations of the same source -- the step
+# kernel and the resident sequence kernel of the mixed batch -- results that differed in the last bit (round 4); with "on" what
+# a step computes is a property of the source: 12-17 more VALU instructions of ~2 500 per kernel, no change in registers.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-         "-fno-slp-vectorize", "-Werror=uninitialized"]
+         "-fno-slp-vectorize", "-Werror=uninitialized", "-ffp-contract=on"]
 
 # The float64 validation kernels of 512-thread groups need all 256 VGPRs, spill ~100 of them to scratch AND spill
 # 200-460 SGPRs.  With the default "SGPR spills live in lanes of reserved VGPRs" the general-expression (non-SYM) ray

@@ -68,6 +68,13 @@ class BatchedDocking3d:
     :param rng: "per_env" -> one legacy ``RandomState`` per env, reference draw order incl. the per-step normal burn
                 (parity with ``reset(seed)`` of the reference); "batched" -> one vectorised generator (throughput)
     :param vehicles: optional per-env vehicle names for a mixed batch, e.g. ["BlueROV2", "LAUV", ...]
+    :param sort_vehicles: mixed batches: keep the envs KIND-SORTED on the device ("for mixed vehicles keep
+                each GPU's range vehicle-sorted": every 64-env group but one is then homogeneous, config 5 15.3 -> 14.5 us per
+                step).  ``perm[j]`` = the caller's index of the env in device row j (stable: the caller's order within a
+                kind), ``inv_perm`` its inverse.  Everything that takes or returns HOST arrays -- step(), reset_envs(),
+                get_field / set_field, seeds, infos, episode storage -- stays in the CALLER's order (rows are permuted at the
+                C-ABI boundary); the device-pointer entry points (step_device, make_step_sequence, ...) work on device rows:
+                row j of the action tensor and of the packed rows belongs to caller env ``perm[j]``.
     """
 
     def __init__(self, env_config: dict = BASE_CONFIG, num_envs: int = 1, scenario: str = "SimpleDocking3d",
@@ -76,7 +83,7 @@ class BatchedDocking3d:
                  max_spheres: Optional[int] = None, threads_per_group: int = 0,
                  vehicle_models: Optional[Sequence[VehicleModel]] = None, current_mu: float = scenarios.CURRENT_MU,
                  reset_mode: Optional[str] = None, device_seed: int = 0, _force_general: bool = False,
-                 device_noise: bool = False):
+                 device_noise: bool = False, sort_vehicles: bool = False):
         if scenario not in scenarios.SCENARIOS:
             raise KeyError(f"Not valid scenario, available options are {scenarios.SCENARIOS}")
         self.config = copy.deepcopy(env_config)
@@ -121,6 +128,13 @@ class BatchedDocking3d:
                 raise ValueError("len(vehicles) must equal num_envs")
         else:
             self.vehicle_id = np.zeros(self.num_envs)
+        # device row j <- caller env perm[j] (identity unless sort_vehicles reorders a mixed batch)
+        self.perm = np.arange(self.num_envs, dtype=np.int64)
+        if sort_vehicles and len(self.vehicle_models) == 2:
+            self.perm = np.argsort(self.vehicle_id, kind="stable").astype(np.int64)
+        self.inv_perm = np.empty_like(self.perm)
+        self.inv_perm[self.perm] = np.arange(self.num_envs, dtype=np.int64)
+        self._sorted = bool((self.perm != np.arange(self.num_envs)).any())
 
         # ray fan (envs/docking3d.py:104-105)
         self.radar_args = self.config["radar"]
@@ -156,6 +170,7 @@ class BatchedDocking3d:
         # host-side episode bookkeeping
         N = self.num_envs
         self._seeds: Optional[np.ndarray] = None
+        self._seed_pending = False      # seeds given (seed() / reset(seed=...)) and not yet applied by a reset
         self._rs: List[Optional[np.random.RandomState]] = [None] * N
         self._gen = np.random.default_rng()
         self._steps_since_reset = np.zeros(N, dtype=np.int64)     # per-step normal draws to burn (current.py:88)
@@ -220,7 +235,20 @@ class BatchedDocking3d:
         return cfg
 
     # ------------------------------------------------------------------------------------------ field I/O
+    def _raw_set(self, field: int, a: np.ndarray, first: int) -> None:
+        rc = self._lib.dockauv_set_field(self._handle, field, first, a.shape[0], a.ctypes.data_as(C.c_void_p))
+        _capi.check(self._lib, self._handle, rc, "dockauv_set_field")
+
+    def _raw_runs(self, field: int, dev_idx: np.ndarray, values: np.ndarray) -> None:
+        """rows `values` to DEVICE rows dev_idx (any order), as contiguous runs"""
+        order = np.argsort(dev_idx, kind="stable")
+        dev_idx, values = dev_idx[order], np.ascontiguousarray(values[order])
+        breaks = np.flatnonzero(np.diff(dev_idx) != 1) + 1
+        for run_idx, run_val in zip(np.split(dev_idx, breaks), np.split(values, breaks)):
+            self._raw_set(field, np.ascontiguousarray(run_val), int(run_idx[0]))
+
     def set_field(self, field: int, values: np.ndarray, first: int = 0) -> None:
+        """Rows of envs [first, first + len(values)) in the caller's order (float64 [count][width])."""
         a = np.ascontiguousarray(values, dtype=np.float64)
         if a.ndim == 1:
             a = a[:, None]
@@ -229,26 +257,35 @@ class BatchedDocking3d:
             return
         if a.shape[1] != width:
             raise ValueError(f"field {field}: expected width {width}, got {a.shape[1]}")
-        rc = self._lib.dockauv_set_field(self._handle, field, first, a.shape[0], a.ctypes.data_as(C.c_void_p))
-        _capi.check(self._lib, self._handle, rc, "dockauv_set_field")
+        if self._sorted:
+            self._raw_runs(field, self.inv_perm[first:first + a.shape[0]], a)
+        else:
+            self._raw_set(field, a, first)
 
     def get_field(self, field: int, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        """Rows of envs [first, first + count) in the caller's order."""
         count = self.num_envs - first if count is None else count
         width = self._lib.dockauv_field_width(self._handle, field)
         out = np.zeros((count, max(width, 0)), dtype=np.float64)
         if width > 0 and count > 0:
-            rc = self._lib.dockauv_get_field(self._handle, field, first, count, out.ctypes.data_as(C.c_void_p))
+            dev = self.inv_perm[first:first + count] if self._sorted else None
+            lo, n = (int(dev.min()), int(dev.max()) - int(dev.min()) + 1) if self._sorted else (first, count)
+            raw = out if not self._sorted else np.zeros((n, width), dtype=np.float64)
+            rc = self._lib.dockauv_get_field(self._handle, field, lo, n, raw.ctypes.data_as(C.c_void_p))
             _capi.check(self._lib, self._handle, rc, "dockauv_get_field")
+            if self._sorted:
+                out = raw[dev - lo]
         return out
 
     def _set_rows(self, field: int, idx: np.ndarray, values: np.ndarray) -> None:
-        """set_field for an arbitrary (sorted) index set, as contiguous runs."""
+        """set_field for an arbitrary index set (caller's env indices), as contiguous runs of device rows."""
         idx = np.asarray(idx)
         if idx.size == 0:
             return
-        breaks = np.flatnonzero(np.diff(idx) != 1) + 1
-        for run_idx, run_val in zip(np.split(idx, breaks), np.split(values, breaks)):
-            self.set_field(field, run_val, first=int(run_idx[0]))
+        values = np.asarray(values, dtype=np.float64)
+        if values.ndim == 1:
+            values = values[:, None]
+        self._raw_runs(field, self.inv_perm[idx] if self._sorted else idx, values)
 
     # convenience views used by callers of the reference (datastorage.py:298-300, train.py:191)
     @property
@@ -285,11 +322,13 @@ class BatchedDocking3d:
         N = self.num_envs
         if seed is None:
             self._seeds = None
+            self._seed_pending = False
             return [None] * N
         seeds = np.asarray(seed)
         if seeds.ndim == 0:
             seeds = int(seeds) + np.arange(N)
         self._seeds = seeds.astype(np.int64)
+        self._seed_pending = True
         return self._seeds.tolist()
 
     def _uniforms(self, idx: np.ndarray, reseed: bool) -> np.ndarray:
@@ -350,7 +389,11 @@ class BatchedDocking3d:
             self.episode_storage.on_reset(idx)
         rc = self._lib.dockauv_reset_envs(self._handle, 0, self.num_envs)
         _capi.check(self._lib, self._handle, rc, "dockauv_reset_envs")
-        self.load_episodes(idx, self.generate_episodes(idx, reseed=seed is not None or self._seeds is not None))
+        # the streams are (re)seeded by the reset that follows seed() / comes with seed=..., and by that one only: a later
+        # reset() without a seed draws on from where the stream stands (envs/docking3d.py:296-298 seeds only `if seed is not
+        # None`; round 4: every reset() re-seeded -- the replay of the reference's multi-episode runs found it)
+        self.load_episodes(idx, self.generate_episodes(idx, reseed=self._seed_pending))
+        self._seed_pending = False
         self.episode += 1
         if self.reset_mode == "pool":
             self.load_episodes(idx, self.generate_episodes_for_pool(idx), pool=True)
@@ -378,8 +421,9 @@ class BatchedDocking3d:
             return
         if self.episode_storage is not None:
             self.episode_storage.on_reset(idx)
-        breaks = np.flatnonzero(np.diff(idx) != 1) + 1
-        for run in np.split(idx, breaks):
+        dev = np.sort(self.inv_perm[idx]) if self._sorted else idx
+        breaks = np.flatnonzero(np.diff(dev) != 1) + 1
+        for run in np.split(dev, breaks):
             rc = self._lib.dockauv_reset_envs(self._handle, int(run[0]), int(run.size))
             _capi.check(self._lib, self._handle, rc, "dockauv_reset_envs")
         self.load_episodes(idx, episodes if episodes is not None else self.generate_episodes(idx))
@@ -415,10 +459,17 @@ class BatchedDocking3d:
         """
         a = np.ascontiguousarray(actions, dtype=self._np_t).reshape(self.num_envs, self.n_u)
         w = None if noise is None else np.ascontiguousarray(noise, dtype=self._np_t).reshape(self.num_envs)
+        if self._sorted:   # the caller's rows -> device rows
+            a = np.ascontiguousarray(a[self.perm])
+            w = None if w is None else np.ascontiguousarray(w[self.perm])
         self._io_keepalive = (a, w)
         io = self._io(a, w, extras)
         rc = self._lib.dockauv_step_host(self._handle, C.byref(io))
         _capi.check(self._lib, self._handle, rc, "dockauv_step_host")
+        if self._sorted:   # ... and the outputs back into the caller's order
+            for buf in (self._obs, self._rew, self._done, self._cond) + ((self._termobs,) if self.auto_reset else ()) + \
+                       ((self._terms, self._nav, self._ray, self._statedot) if extras else ()):
+                buf[...] = buf[self.inv_perm]
         self.t_total_steps += 1
         self._steps_since_reset += 1
         done = self._done.astype(bool)
@@ -478,9 +529,11 @@ class BatchedDocking3d:
     def enable_trace(self, env_ids: Sequence[int], capacity: int) -> None:
         """Device ring of the last `capacity` steps of the selected envs (dockauv_trace_enable); [] switches it off."""
         ids = np.ascontiguousarray(sorted(int(i) for i in env_ids), dtype=np.int32)
-        rc = self._lib.dockauv_trace_enable(self._handle, ids.ctypes.data_as(C.c_void_p), int(ids.size), int(capacity))
+        dev = np.ascontiguousarray(np.sort(self.inv_perm[ids]), dtype=np.int32) if (self._sorted and ids.size) else ids
+        rc = self._lib.dockauv_trace_enable(self._handle, dev.ctypes.data_as(C.c_void_p), int(dev.size), int(capacity))
         _capi.check(self._lib, self._handle, rc, "dockauv_trace_enable")
-        self._trace_ids = ids
+        # ring row j belongs to the j-th DEVICE row selected: the caller's ids in that order
+        self._trace_ids = np.ascontiguousarray(self.perm[dev], dtype=np.int32) if (self._sorted and ids.size) else ids
 
     def trace_steps(self) -> int:
         return int(self._lib.dockauv_trace_steps(self._handle))

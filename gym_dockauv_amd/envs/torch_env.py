@@ -43,6 +43,10 @@ class TorchDocking3d:
                         for _ in range(n_buf)]
         self._terminal = None
         self._i = 0
+        # mixed batches built with sort_vehicles=True: row j of every tensor handed in / out belongs to the caller's env
+        # perm[j] (kind-sorted on the device, the caller's order within a kind); identity otherwise
+        self.perm = torch.as_tensor(self.batch.perm, device=self.device)
+        self.vehicles_by_row = None if vehicles is None else [list(vehicles)[int(i)] for i in self.batch.perm]
 
     def reset(self, seed: Optional[int] = None):
         """All envs: new episodes; returns the reference's reset observation (zeros, docking3d.py:269,322)."""
@@ -141,8 +145,25 @@ class ShardedTorchDocking3d:
         torch.cuda.set_device(self.device)
         self.num_envs = int(num_envs)
         self.first, self.n_local = shard_range(self.num_envs, self.world, self.rank)
+        # Mixed batches with sort_vehicles=True (a keyword passed on to the shard's batch): every rank keeps ITS contiguous
+        # range of the caller's envs and sorts it by vehicle kind on its device; global row j of the
+        # gathered tensors -- and of a global action batch -- then belongs to the caller's env perm[j] (computed identically
+        # on every rank from the full vehicle list; identity without the option)
+        perm = np.arange(self.num_envs, dtype=np.int64)
         if vehicles is not None:
-            vehicles = list(vehicles)[self.first:self.first + self.n_local]
+            vehicles = list(vehicles)
+            if len(vehicles) != self.num_envs:
+                raise ValueError("len(vehicles) must equal num_envs (the total over all ranks)")
+            if kw.get("sort_vehicles"):
+                kinds = np.array([0 if v == "BlueROV2" else 1 for v in vehicles])
+                for r in range(self.world):
+                    f, n = shard_range(self.num_envs, self.world, r)
+                    perm[f:f + n] = f + np.argsort(kinds[f:f + n], kind="stable")
+            self.vehicles_by_row = [vehicles[int(i)] for i in perm]
+            vehicles = vehicles[self.first:self.first + self.n_local]
+        else:
+            self.vehicles_by_row = None
+        self.perm = perm
         self.batch = BatchedDocking3d(env_config, num_envs=self.n_local, scenario=scenario, device=device, precision="f32",
                                       reset_mode="device", device_seed=device_seed + self.rank, rng="batched",
                                       vehicles=vehicles, **kw)

@@ -2,7 +2,7 @@
 # VGPR / SGPR / scratch / occupancy / LDS / instruction mix of every f32 step-kernel instantiation (cross-compiles, no GPU)
 #   bash scripts/kernel_usage.sh [extra -D flags] > profiles/r3/kernel_usage.txt
 cd "$(dirname "$0")/../gym_dockauv_amd/csrc"
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-slp-vectorize "$@" -S --cuda-device-only dockauv_kernels_f32.hip -o /tmp/k32.s -Rpass-analysis=kernel-resource-usage 2> /tmp/k32.usage
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-slp-vectorize -ffp-contract=on "$@" -S --cuda-device-only dockauv_kernels_f32.hip -o /tmp/k32.s -Rpass-analysis=kernel-resource-usage 2> /tmp/k32.usage
 python3 - <<'PY'
 import re, subprocess
 from collections import Counter
