@@ -497,8 +497,9 @@ def self_launch(n: int) -> int:
     base.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     children = []
+    share = os.environ.get("DOCKAUV_RANKS_SHARE_GPU") == "1"   # rehearsal on a one-GPU box (with DOCKAUV_DIST_BACKEND=gloo)
     for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        env = dict(base, RANK=str(r), LOCAL_RANK="0" if share else str(r))
         children.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
     import threading
     chunks = []
