@@ -18,4 +18,4 @@ for s in rows:
           f"{r.get('us_per_step_events', float('nan')):11.2f} {r.get('frac_of_8TBps', float('nan')):6.3f} {r.get('vs_per_launch') or float('nan'):6.3f} "
           f"{cl.get('us_per_step', float('nan')):9.2f}")
 for sw in d.get("sweep", []):
-    print(f"sweep envs {sw['envs']:8d}  kernel_us {sw['kernel_us']:8.2f}  frac {sw['frac_of_8TBps']:.3f}")
+    print(f"sweep envs {sw['envs']:8d}  kernel_us {sw['kernel_us']:8.2f}  frac {sw['frac_of_8TBps']:.3f}  resident_us {sw.get('sequence_resident_us_per_step') or float('nan'):8.2f}  frac {sw.get('sequence_resident_frac_of_8TBps') or float('nan'):.3f}")
