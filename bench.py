@@ -218,6 +218,13 @@ def roofline_of(config_id: int, envs: int, kernel_us: float, n_timed: int, ksha:
          "traffic": None, "kernel": "dockauv::step_kernel", "kernel_us": kernel_us,
          "algorithmic_bytes_per_env_step": ALGO_BYTES[config_id], "envs_per_launch": envs,
          "timing": (KERNEL_TIMING + f"; {n_timed} launches") if isinstance(n_timed, int) else str(n_timed)}
+    # what the launch touches (state, obstacles, the action ring, rows): below the 256 MiB Infinity Cache the "HBM" fraction is
+    # measured on cache-resident data (FETCH_SIZE counts MALL hits as well); the sweep's 1 048 576-env point is the one that
+    # streams from HBM proper
+    ws = bytes_per_launch * 1.3
+    r["working_set_note"] = (f"~{ws / 2**20:.0f} MiB touched per launch: " +
+                             ("fits the 256 MiB Infinity Cache -- the HBM-resident operating points are the sweep's (262 144 / 1 048 576 envs)"
+                              if ws < 200 * 2**20 else "beyond the 256 MiB Infinity Cache: streams from HBM"))
     e = pmc_entry(config_id, envs, "dense" if dense else variant)
     if e:
         stale = e.get("kernel_sha") != ksha
