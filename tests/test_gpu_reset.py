@@ -457,3 +457,49 @@ def test_vehicle_sorted_batch_equals_caller_ordered_batch(precision, tmp_path):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.gpu
+def test_torch_envs_hand_back_the_vehicle_permutation():
+    """TorchDocking3d / ShardedTorchDocking3d (one rank) with sort_vehicles=True: rows come out in device order together with
+    `perm` (row j = the caller's env perm[j]) and `vehicles_by_row`; permuted back they are the unsorted env's rows, bit for bit."""
+    import copy
+    import torch
+    from gym_dockauv_amd.config.env_config import BASE_CONFIG
+    from gym_dockauv_amd.envs.torch_env import ShardedTorchDocking3d, TorchDocking3d
+    cfg = copy.deepcopy(BASE_CONFIG)
+    cfg["t_step_size"] = 0.02
+    N = 300
+    kinds = ["BlueROV2" if (i * 7) % 3 else "LAUV" for i in range(N)]
+    ref = TorchDocking3d(cfg, num_envs=N, scenario="ObstaclesCurrentDocking3d", reset_mode="none", vehicles=kinds)
+    srt = TorchDocking3d(cfg, num_envs=N, scenario="ObstaclesCurrentDocking3d", reset_mode="none", vehicles=kinds, sort_vehicles=True)
+    shd = ShardedTorchDocking3d(cfg, num_envs=N, scenario="ObstaclesCurrentDocking3d", vehicles=kinds, sort_vehicles=True, host_seed=4)
+    try:
+        for e in (ref, srt):
+            e.batch._gen = np.random.default_rng(4)
+        ref.reset()
+        srt.reset()
+        shd.reset()
+        # the same episodes everywhere: copy the unsorted env's fields through the caller-ordered host API
+        for f in (0, 2, 3, 5):   # state, goal, current, capsules
+            rows = ref.batch.get_field(f)
+            for e in (ref, srt, shd):   # (ref too: a read-back current has float32 angles, its direction is recomputed from them)
+                e.batch.set_field(f, rows)
+        perm = srt.perm
+        assert srt.vehicles_by_row == [kinds[int(i)] for i in perm.cpu()] and srt.vehicles_by_row == sorted(kinds)
+        assert torch.equal(perm.cpu(), torch.as_tensor(shd.perm)) and shd.vehicles_by_row == srt.vehicles_by_row
+        g = torch.Generator(device=ref.device)
+        g.manual_seed(1)
+        for t in range(12):
+            a = torch.rand((N, ref.n_u), device=ref.device, generator=g) * 2 - 1
+            o0, r0, d0 = ref.step(a)
+            o1, r1, d1 = srt.step(a[perm].contiguous())
+            o2, r2, d2 = shd.step(a[perm].contiguous())
+            assert torch.equal(o0[perm], o1) and torch.equal(r0[perm], r1) and torch.equal(d0[perm], d1), f"TorchDocking3d, step {t}"
+            # (the sharded env resets in-kernel, the other two do not: compared while no episode has ended)
+            assert not bool(d0.any()), "choose fewer steps: an episode ended"
+            assert torch.equal(o0[perm], o2) and torch.equal(r0[perm], r2) and torch.equal(d0[perm], d2), f"ShardedTorchDocking3d, step {t}"
+    finally:
+        ref.close()
+        srt.close()
+        shd.close()
