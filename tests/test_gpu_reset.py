@@ -125,7 +125,7 @@ SEQ_CASES = {
     # name: (bench config id or scenario kwargs, envs, threads)
     "config2_256": (2, 777, 0), "config2_128": (2, 1000, 128), "config2_64": (2, 1000, 64),
     "config3_256": (3, 777, 0), "config3_64": (3, 1000, 64),
-    "config4_512": (4, 777, 512), "config4_256": (4, 777, 256),
+    "config4_512": (4, 777, 512), "config4_256": (4, 777, 256), "config4_64": (4, 1000, 64),
     "config5_256": (5, 778, 0), "config5_64": (5, 778, 64),
 }
 
