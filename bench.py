@@ -447,6 +447,54 @@ def measure_ray_dense(config_id, args, torch, dev, local_rank, rank, ksha):
     return res
 
 
+# configs 4 / 5 beyond residency: BASELINE's total env count of the config (what its eight GPUs share) and 1 048 576
+BEYOND_RESIDENCY = {4: (262144, 1048576), 5: (524288, 1048576)}
+
+
+def sweep_point(wl, config_id, n_big, n_base, args, torch, dev, local_rank, stream, gen):
+    """The workload's kernel at a batch size beyond residency (launches of several rounds of groups; the state no longer fits
+    the caches: the HBM-relevant roofline points), per launch and as resident sequences: regions of 128 steps."""
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    e2 = BatchedDocking3d(wl["cfg"], num_envs=n_big, scenario=wl["scenario"], device=local_rank, precision="f32",
+                          reset_mode="device", device_seed=0xABC, rng="batched",
+                          vehicles=(wl["vehicles"] * (n_big // n_base + 1))[:n_big] if wl["vehicles"] else None)
+    e2._gen = np.random.default_rng(7)
+    e2.reset()
+    e2.set_sequence_resident(False)
+    n_obs, n_u = e2.n_observations, e2.n_u
+    a2 = torch.rand((4, n_big, n_u), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
+    o2 = torch.zeros((n_big, n_obs + 2), device=dev, dtype=torch.float32)
+    KS = 128   # (regions of 20 launches, rounds 1-3, carried the first launches' cold caches: 121 us against 108)
+    seq2 = e2.make_step_sequence([a2[r % 4].data_ptr() for r in range(KS)], [o2.data_ptr()] * KS, packed=True)
+
+    def region_us(reps):
+        e2.run_step_sequence(seq2, stream=stream)
+        torch.cuda.synchronize()
+        ev = []
+        for r in range(reps):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            e2.run_step_sequence(seq2, stream=stream)
+            ev1.record()
+            torch.cuda.synchronize()
+            ev.append(ev0.elapsed_time(ev1) / KS * 1e3)
+        return statistics.median(ev)
+    us = region_us(5)
+    e2.set_sequence_resident(True)
+    us_res = None if args.no_resident else region_us(5)
+    threads = getattr(e2, "threads_in_use", None)
+    gbps = ALGO_BYTES[config_id] * n_big / (us * 1e-6) / 1e9
+    res = {"envs": n_big, "kernel_us": us, "env_steps_per_s_kernel": n_big / (us * 1e-6),
+           "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS,
+           "sequence_resident_us_per_step": us_res,
+           "sequence_resident_frac_of_8TBps": (ALGO_BYTES[config_id] * n_big / (us_res * 1e-6) / 1e9 / HBM_PEAK_GBPS) if us_res else None}
+    if threads:
+        res["threads_per_group"] = threads
+    e2.close()
+    del a2, o2
+    return res
+
+
 def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, kernel_launches=512, layout=""):
     """One workload on this GPU alone (no collective): open-loop regions, kernel duration by events, closed loop."""
     wl = workload(config_id, envs, layout)
@@ -486,6 +534,10 @@ def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, ke
         res["kernel_us_isolated_launches"] = iso
     env.close()
     del actions, out
+    if config_id in BEYOND_RESIDENCY and not layout and not envs and not args.no_sweep:
+        # the 8-GPU workloads as ONE GPU would run them whole, and at 1 048 576 envs (one wave per group there: dockauv_create)
+        res["beyond_residency"] = [sweep_point(wl, config_id, n_big, N, args, torch, dev, local_rank, stream, gen)
+                                   for n_big in BEYOND_RESIDENCY[config_id]]
     return res
 
 
@@ -847,41 +899,8 @@ def main():
     sweep = []
     if world == 1 and not args.no_sweep and not args.envs:
         # the same kernel at batch sizes where the state no longer fits the caches (HBM-relevant roofline points)
-        from gym_dockauv_amd.envs.batched import BatchedDocking3d
         for n_big in args.sweep:
-            e2 = BatchedDocking3d(wl["cfg"], num_envs=n_big, scenario=wl["scenario"], device=local_rank, precision="f32",
-                                  reset_mode="device", device_seed=0xABC, rng="batched",
-                                  vehicles=(wl["vehicles"] * (n_big // N + 1))[:n_big] if wl["vehicles"] else None)
-            e2._gen = np.random.default_rng(7)
-            e2.reset()
-            e2.set_sequence_resident(False)
-            a2 = torch.rand((4, n_big, n_u), device=dev, generator=gen, dtype=torch.float32) * 2 - 1
-            o2 = torch.zeros((n_big, n_obs + 2), device=dev, dtype=torch.float32)
-            KS = 128   # (regions of 20 launches, rounds 1-3, carried the first launches' cold caches: 121 us against 108)
-            seq2 = e2.make_step_sequence([a2[r % 4].data_ptr() for r in range(KS)], [o2.data_ptr()] * KS, packed=True)
-
-            def region_us(reps):
-                e2.run_step_sequence(seq2, stream=stream)
-                torch.cuda.synchronize()
-                ev = []
-                for r in range(reps):
-                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    ev0.record()
-                    e2.run_step_sequence(seq2, stream=stream)
-                    ev1.record()
-                    torch.cuda.synchronize()
-                    ev.append(ev0.elapsed_time(ev1) / KS * 1e3)
-                return statistics.median(ev)
-            us = region_us(5)
-            e2.set_sequence_resident(True)
-            us_res = None if args.no_resident else region_us(5)
-            gbps = ALGO_BYTES[config_id] * n_big / (us * 1e-6) / 1e9
-            sweep.append({"envs": n_big, "kernel_us": us, "env_steps_per_s_kernel": n_big / (us * 1e-6),
-                          "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS,
-                          "sequence_resident_us_per_step": us_res,
-                          "sequence_resident_frac_of_8TBps": (ALGO_BYTES[config_id] * n_big / (us_res * 1e-6) / 1e9 / HBM_PEAK_GBPS) if us_res else None})
-            e2.close()
-            del a2, o2
+            sweep.append(sweep_point(wl, config_id, n_big, N, args, torch, dev, local_rank, stream, gen))
 
     if not use_dist:
         collective = "none"

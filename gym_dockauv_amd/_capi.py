@@ -101,6 +101,7 @@ SYMBOLS = [
     ("dockauv_create", C.c_int, [C.POINTER(Config), C.c_int, C.POINTER(C.c_void_p)]),
     ("dockauv_destroy", C.c_int, [C.c_void_p]),
     ("dockauv_n_obs", C.c_int, [C.c_void_p]),
+    ("dockauv_threads_per_group", C.c_int, [C.c_void_p]),
     ("dockauv_n_rays", C.c_int, [C.c_void_p]),
     ("dockauv_n_u", C.c_int, [C.c_void_p]),
     ("dockauv_field_width", C.c_int, [C.c_void_p, C.c_int]),

@@ -433,11 +433,20 @@ int dockauv_create(const dockauv_config* cfg, int device, dockauv_handle* out) {
         // fan (config 3, 16 beams x 8 spheres) 64 against 256 threads: 131 072 envs 18.4 / 16.7 us, 196 608: 23.0 / 26.0,
         // 262 144: 27.0 / 34.3, 524 288: 50.9 / 69.3, 1 048 576: 117.9 / 175.7; heavy fan (config 4, 63 rays x 5 capsules):
         // 524 288: 115.6 / 113.7, 1 048 576: 236 / 251; mixed vehicles (config 5): 256 threads at every size (229 / 251 at 1 M).
+        // One-wave groups of the 63-ray fan against <= 5 capsules keep their completed records in registers (float32:
+        // dockauv_step.hip.inc: regrec; 8 -> 16 groups per CU); 64 against 256 threads with that (profiles/r4/threads_large.txt,
+        // second table): config 4 163 840 envs 41.4 / 38.2 us, 196 608: 43.1 / 43.8, 262 144: 51.0 / 56.9, 393 216: 69.3 / 82.8,
+        // 1 048 576: 154 / 246; config 5 (mixed) 262 144: 53.6 / 50.0, 393 216: 74.5 / 73.9, 524 288: 86.3 / 94.7,
+        // 1 048 576: 161 / 215 (vehicle-sorted: 154 / 211).
         const long tests = (long)h->n_rays * (c.max_capsules + c.max_spheres);
         const bool light = tests < 256;
+        int pad_log2 = 0;
+        while ((1 << pad_log2) < h->n_rays) ++pad_log2;
+        const bool regrec = !h->f64 && solo_regrec(c.max_capsules, c.max_spheres, pad_log2);
         if (!light && c.n_envs <= 32768) h->threads = 512;
-        else if (light ? c.n_envs > 163840 : (c.n_vehicles == 1 && c.n_envs > 786432)) h->threads = 64;
-        else h->threads = 256;
+        else if (light) h->threads = c.n_envs > 163840 ? 64 : 256;
+        else if (regrec) h->threads = c.n_envs > (c.n_vehicles == 1 ? 196608 : 393216) ? 64 : 256;
+        else h->threads = (c.n_vehicles == 1 && c.n_envs > 786432) ? 64 : 256;
     }
     if (c.n_vehicles == 2) {
         if (!(c.vehicle[0].kind == DOCKAUV_VEH_CONSTB && b_is_diagonal(c.vehicle[0]) && c.vehicle[1].kind == DOCKAUV_VEH_LAUV)) {
@@ -618,6 +627,7 @@ int dockauv_destroy(dockauv_handle h) {
 }
 
 int dockauv_n_obs(dockauv_handle h) { return h ? h->n_obs : DOCKAUV_E_INVALID; }
+int dockauv_threads_per_group(dockauv_handle h) { return h ? h->threads : DOCKAUV_E_INVALID; }
 int dockauv_n_rays(dockauv_handle h) { return h ? h->n_rays : DOCKAUV_E_INVALID; }
 int dockauv_n_u(dockauv_handle h) { return h ? h->n_u_max : DOCKAUV_E_INVALID; }
 

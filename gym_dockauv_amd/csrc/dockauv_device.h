@@ -191,8 +191,21 @@ constexpr int kNavFields = 5;    // integrating wave -> tail roles (SHARE_NAV): 
                                  // they live in spare rows of the obstacle-avoidance sums (dockauv_step.hip.inc: lds_nav)
 constexpr int kHxFields = 21;    // env phase -> tail waves: state (12), V_c, action penalty, |euler_dot|^2, collision, nu_c (3), sin/cos psi
 
+// one-wave groups whose completed capsule records stay in registers (dockauv_step.hip.inc: regrec): the 63-ray fan (one env
+// per 64-lane pass) against at most kRegCaps capsules and no spheres, float32
+constexpr int kRegCaps = 5;
+constexpr bool solo_regrec(int max_cap, int max_sph, int ray_pad_log2) {
+    return max_sph == 0 && max_cap >= 1 && max_cap <= kRegCaps && ray_pad_log2 == 6;
+}
+
 template <typename T>
-inline size_t lds_bytes(int epg, int nt, int max_cap, int max_sph, int n_obs, bool rays) {
+inline size_t lds_bytes(int epg, int nt, int max_cap, int max_sph, int n_obs, bool rays, int ray_pad_log2 = 0) {
+    if (rays && nt / epg == 1 && sizeof(T) == 4 && solo_regrec(max_cap, max_sph, ray_pad_log2)) {
+        // raw capsule rows [max_cap][7][epg]; over them, once the records are complete, the tile
+        const size_t raw = (size_t)epg * 7 * max_cap * sizeof(T);
+        const size_t tile = (size_t)epg * (n_obs + 2) * sizeof(float);
+        return ((raw > tile ? raw : tile) + 15) & ~(size_t)15;
+    }
     if (rays && nt / epg == 1) {
         // one-wave ray groups (dockauv_step.hip.inc: SOLO): no pose rows (registers); the observation tile overlays the
         // obstacle records; behind the larger of the two: obstacle-avoidance sums (2 rows), the list of active envs (1 row),

@@ -164,6 +164,7 @@ class BatchedDocking3d:
         rc = self._lib.dockauv_create(C.byref(cfg), self.device, C.byref(self._handle))
         _capi.check(self._lib, None, rc, "dockauv_create")
         assert self._lib.dockauv_n_obs(self._handle) == self.n_observations
+        self.threads_in_use = int(self._lib.dockauv_threads_per_group(self._handle))   # (the library's choice when 0 was asked)
         if len(self.vehicle_models) == 2:
             self.set_field(_capi.F_VEHICLE_ID, self.vehicle_id[:, None])
 

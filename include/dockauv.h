@@ -197,6 +197,9 @@ int dockauv_destroy(dockauv_handle h);
 
 /* derived sizes: n_obs = 16 + n_rays_reduced (docking3d.py:114-115), n_rays (sensor.py:63), n_u_max */
 int dockauv_n_obs(dockauv_handle h);
+/* waves x 64 = threads per 64-env group the handle's step kernels run with (dockauv_config::threads_per_group, or the
+ * library's choice for this workload and batch size when that was 0).  No reference counterpart: a tuning read-out. */
+int dockauv_threads_per_group(dockauv_handle h);
 int dockauv_n_rays(dockauv_handle h);
 int dockauv_n_u(dockauv_handle h);
 

@@ -113,6 +113,46 @@ def test_one_wave_ray_groups_vs_reference(which, precision):
     run_tiled(names, 1000, precision, threads=64)
 
 
+def test_group_shape_the_library_picks():
+    """threads_per_group = 0: dockauv_create's choice by workload and batch size (dockauv_capi.hip; the tables behind it:
+    profiles/r4/threads_large.txt), read back through dockauv_threads_per_group."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from gym_dockauv_amd.envs.batched import BatchedDocking3d
+    expect = {(2, 4096): 256, (2, 131072): 128, (2, 262144): 64,
+              (3, 65536): 256, (3, 262144): 64,
+              (4, 32768): 512, (4, 65536): 256, (4, 196608): 256, (4, 262144): 64,
+              (5, 65536): 256, (5, 262144): 256, (5, 524288): 64}
+    for (cid, n), threads in expect.items():
+        wl = bench.workload(cid, n)
+        env = BatchedDocking3d(wl["cfg"], num_envs=n, scenario=wl["scenario"], precision="f32", reset_mode="device", device_seed=1,
+                               rng="batched", vehicles=wl["vehicles"])
+        try:
+            assert env.threads_in_use == threads, (cid, n, env.threads_in_use, threads)
+        finally:
+            env.close()
+    # float64 has no register-resident records: the one-wave shape of a heavy fan starts where it did before
+    wl = bench.workload(4, 262144)
+    env = BatchedDocking3d(wl["cfg"], num_envs=262144, scenario=wl["scenario"], precision="f64", reset_mode="device", device_seed=1,
+                           rng="batched")
+    try:
+        assert env.threads_in_use == 256
+    finally:
+        env.close()
+
+
+@pytest.mark.parametrize("which", ["lauv_near", "mixed_near"])
+def test_one_wave_capsule_groups_at_the_size_that_selects_them(which):
+    """Config 4 beyond 196 608 envs and mixed batches beyond 393 216 run ONE wave per group with the completed capsule
+    records in registers (dockauv_step.hip.inc: regrec); here at the smallest batches that select that shape by themselves
+    (threads_per_group = 0), every env against the reference's rows (ray-rich fixtures)."""
+    names, n = {"lauv_near": (["traj_ObstaclesDocking3d_lauv_near"], 196608 + 64),
+                "mixed_near": (MIXED_PAIRS["near"], 393216 + 64)}[which]
+    run_tiled(names, n)
+
+
 # "_near": vehicles that start 4-6 m from a capsule and face it -- 30-50 % of all rays in range, every step with hits
 # (oracle/gen_golden.py: gen_near_obstacles); the older LAUV trajectories never have a ray in range (min_ray = 10.0)
 MIXED_PAIRS = {
