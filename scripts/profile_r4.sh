@@ -55,6 +55,9 @@ prof config2_1M --config 2 --envs 1048576 --steps 200 --warmup 20
 prof config3_1M --config 3 --envs 1048576 --steps 200 --warmup 20
 prof config4_1M --config 4 --envs 1048576 --steps 100 --warmup 20
 prof config5_1M --config 5 --envs 1048576 --steps 100 --warmup 20
+# BASELINE's totals of configs 4 / 5 (what their eight GPUs share) on ONE GPU: one-wave groups, capsule records in registers
+prof config4_262k --config 4 --envs 262144 --steps 200 --warmup 20
+prof config5_524k --config 5 --envs 524288 --steps 200 --warmup 20
 # the resident step sequence (dockauv_step_sequence's fast path): rocprofv3 kernel stats of step_seq_kernel (one dispatch = up to
 # 64 steps) next to the bench line's own per-step figure
 for c in 2 3 4 5; do
@@ -83,7 +86,8 @@ out = {}
 for name, key in (("config2", "config2_envs4096"), ("config3", "config3_envs65536"), ("config4", "config4_envs32768"),
                   ("config5", "config5_envs65536"), ("config5_sorted", "config5_sorted_envs65536"), ("config3_dense", "config3_dense_envs65536"),
                   ("config4_dense", "config4_dense_envs32768"), ("config2_1M", "config2_envs1048576"), ("config3_1M", "config3_envs1048576"),
-                  ("config4_1M", "config4_envs1048576"), ("config5_1M", "config5_envs1048576")):
+                  ("config4_1M", "config4_envs1048576"), ("config5_1M", "config5_envs1048576"),
+                  ("config4_262k", "config4_envs262144"), ("config5_524k", "config5_envs524288")):
     e = {"source": f"profiles/r4/{name}/", "kernel_sha": sha}
     try:
         d = json.loads(open(os.path.join(root, name, "pmc_summary.txt")).read().strip().splitlines()[-1])

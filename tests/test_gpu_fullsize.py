@@ -21,8 +21,9 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def run_tiled(names, n_envs, precision="f32", threads=0):
-    """names: one golden trajectory, or two for a mixed batch (env j uses names[j % 2])."""
+def run_tiled(names, n_envs, precision="f32", threads=0, split=None):
+    """names: one golden trajectory, or two for a mixed batch (env j uses names[j % 2]; with `split`: a KIND-SORTED batch, the
+    envs [0, split) use names[0], the envs [split, n_envs) names[1])."""
     from gym_dockauv_amd.envs.batched import BatchedDocking3d
     gs = [H.load(n) for n in names]
     K = len(gs)
@@ -35,7 +36,8 @@ def run_tiled(names, n_envs, precision="f32", threads=0):
     max_sph = max(int(g["ep_sph_radii"].shape[1]) for g in gs)
     vehicles = None
     if K == 2:
-        vehicles = [str(gs[j % 2]["meta_vehicle"]) for j in range(n_envs)]
+        kind_of = (lambda j: j % 2) if split is None else (lambda j: int(j >= split))
+        vehicles = [str(gs[kind_of(j)]["meta_vehicle"]) for j in range(n_envs)]
         assert sorted(set(vehicles)) == ["BlueROV2", "LAUV"]
     env = BatchedDocking3d(cfg, num_envs=n_envs, scenario=H.scenario_of(gs[0]), precision=precision, auto_reset=False,
                            max_capsules=max_caps, max_spheres=max_sph, current_mu=float(gs[0]["ep_current"][0, 0]),
@@ -44,8 +46,13 @@ def run_tiled(names, n_envs, precision="f32", threads=0):
         # env j -> trajectory j % K, golden step (j // K) % T
         parts = []
         for k, g in enumerate(gs):
-            envs_k = np.arange(k, n_envs, K)
-            parts.append((envs_k, H.teacher_forced_inputs(g, (envs_k // K) % int(g["meta_T"]), max_caps, max_sph)))
+            if split is None:
+                envs_k = np.arange(k, n_envs, K)
+                steps_k = envs_k // K
+            else:
+                envs_k = np.arange(0, split) if k == 0 else np.arange(split, n_envs)
+                steps_k = envs_k - envs_k[0]
+            parts.append((envs_k, H.teacher_forced_inputs(g, steps_k % int(g["meta_T"]), max_caps, max_sph)))
 
         def merge(get):
             first = get(parts[0][1])
@@ -77,7 +84,7 @@ def run_tiled(names, n_envs, precision="f32", threads=0):
         assert np.array_equal(env.t_steps, gold["t_steps"])
         # the batch is made of copies: copies of the same golden step must also agree with each other bit for bit
         T0 = int(gs[0]["meta_T"]) * K
-        if n_envs >= 2 * T0:
+        if n_envs >= 2 * T0 and split is None:
             assert np.array_equal(obs[:T0], obs[T0:2 * T0]) and np.array_equal(rew[:T0], rew[T0:2 * T0])
         return res
     finally:
@@ -175,6 +182,15 @@ def test_config4_full_size(name):
 @pytest.mark.parametrize("pair", sorted(MIXED_PAIRS))
 def test_config5_mixed_full_size(pair):
     run_tiled(MIXED_PAIRS[pair], 65536)
+
+
+@pytest.mark.parametrize("pair,n,split", [("near", 65536, 32768), ("random", 65536, 32768), ("near", 1000, 437), ("near", 262144 + 128, 131072 + 1)])
+def test_config5_kind_sorted_vs_reference(pair, n, split):
+    """A KIND-SORTED mixed batch (every BlueROV2 env in front of every LAUV env: BatchedDocking3d(sort_vehicles=True)'s device
+    layout): every group but one holds ONE vehicle kind, one of the mixed kernel's two integrating waves owns all 64 lanes and
+    the other none.  Every env against the reference's rows: config 5's size with the split on a group boundary, a small batch
+    with an odd split (a group of both kinds in the middle), and the write-back twin beyond 262 144 envs."""
+    run_tiled(MIXED_PAIRS[pair], n, split=split)
 
 
 @pytest.mark.parametrize("pair", sorted(MIXED_PAIRS))
