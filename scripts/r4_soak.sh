@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 4 soak: every BASELINE config + config 3 at 1 048 576 envs (one wave per group) for SOAK_SECONDS each, per launch AND as
+# round 4 soak: every BASELINE config + configs 3 / 4 / 5 beyond residency (one wave per group; 4 / 5: capsule records in registers)
+# for SOAK_SECONDS each, per launch AND as
 # resident step sequences; rows finite, status word clean, auto-resets going -> gpurun_out/r4/soak.txt
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4
@@ -7,7 +8,7 @@ python - <<'PY' | tee gpurun_out/r4/soak.txt
 import os, time, numpy as np, torch, bench
 dev = torch.device("cuda", 0)
 secs = float(os.environ.get("SOAK_SECONDS", "8"))
-for cid, envs in ((2, 0), (3, 0), (4, 0), (5, 0), (3, 1048576), (4, 1048576)):
+for cid, envs in ((2, 0), (3, 0), (4, 0), (5, 0), (3, 1048576), (4, 1048576), (5, 1048576), (4, 262144), (5, 524288)):
     for resident in (False, True):
         wl = bench.workload(cid, envs)
         env = bench.make_env(wl, 0, 0, 0)
