@@ -541,6 +541,15 @@ def measure_single(config_id, envs, args, torch, dev, local_rank, rank, ksha, ke
     return res
 
 
+def split_json_line(out: str):
+    """(the LAST line of `out` that is a JSON object, every other line) -- (None, []) if there is none."""
+    lines = out.splitlines()
+    js = [k for k, ln in enumerate(lines) if ln.lstrip().startswith("{") and ln.rstrip().endswith("}")]
+    if not js:
+        return None, []
+    return lines[js[-1]].strip(), [ln for k, ln in enumerate(lines) if k != js[-1]]
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` started without a launcher: become one.  N child rank processes of this very command line
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) are started BEFORE this process imports torch
@@ -582,7 +591,13 @@ def self_launch(n: int) -> int:
     drain.join(timeout=30)
     out = b"".join(chunks).decode(errors="replace")
     if rc == 0:
-        sys.stdout.write(out)
+        # ONE JSON line on stdout: whatever else rank 0's stdout carried (a collective library's banner, e.g. "[Gloo] Rank 0
+        # is connected to ...") goes to stderr
+        line, others = split_json_line(out)
+        if others:
+            sys.stderr.write("\n".join(others) + "\n")
+            sys.stderr.flush()
+        sys.stdout.write(line + "\n" if line is not None else out)
         sys.stdout.flush()
     else:
         sys.stderr.write(out)

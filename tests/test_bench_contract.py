@@ -98,6 +98,16 @@ def test_gpus_n_launches_its_own_ranks():
         assert "stopping the other ranks" in err
 
 
+def test_launcher_relays_exactly_the_json_line():
+    """rank 0's stdout may carry a collective library's banner in front of the line (gloo prints one): the launcher hands
+    on the JSON line alone."""
+    line, others = bench.split_json_line('[Gloo] Rank 0 is connected to 1 peer ranks.\n{"metric": "m", "value": 1.0}\n')
+    assert json.loads(line) == {"metric": "m", "value": 1.0} and others == ["[Gloo] Rank 0 is connected to 1 peer ranks."]
+    assert bench.split_json_line("no line here\n") == (None, [])
+    line, others = bench.split_json_line('{"a": 1}\nnoise\n{"b": 2}\n')
+    assert json.loads(line) == {"b": 2} and others == ['{"a": 1}', "noise"]
+
+
 def test_world_size_must_match_gpus():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", HIP_VISIBLE_DEVICES="")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
