@@ -98,3 +98,55 @@ def test_oversized_batch_rejected(lib):
     assert lib.dockauv_p2p_push(None, 16, None, 1, None) == -1
     assert lib.dockauv_p2p_gather(None, None, 1, 1, None) == -1
     assert b"dockauv_p2p_gather" in lib.dockauv_last_error(None)
+
+
+def test_empty_batch_and_bad_shapes_rejected_before_any_device_call(lib):
+    """dockauv_create validates its configuration before it touches a device: an empty batch, an unknown precision, too
+    many obstacle slots, an empty or oversized ray fan and a zero step size all come back as DOCKAUV_E_INVALID with a
+    message naming the field (the reference has no batch: its envs are built one at a time, `envs/docking3d.py:74-220`)."""
+    from gym_dockauv_amd import _capi
+
+    def good():
+        cfg = _capi.Config()
+        cfg.struct_size = C.sizeof(_capi.Config)
+        cfg.abi_version = _capi.ABI_VERSION
+        cfg.n_envs = 64
+        cfg.precision = _capi.F32
+        cfg.n_vehicles = 1
+        cfg.n_v, cfg.n_h, cfg.blocksize_reduce = 7, 9, 2
+        cfg.reward_set = 1
+        cfg.t_step_size = 0.1
+        return cfg
+
+    def rejected(cfg, needle):
+        h = C.c_void_p()
+        rc = lib.dockauv_create(C.byref(cfg), 0, C.byref(h))
+        msg = lib.dockauv_last_error(None)
+        assert rc == -1 and not h.value and needle in msg, (rc, msg)
+
+    for n in (0, -5):
+        cfg = good(); cfg.n_envs = n
+        rejected(cfg, b"n_envs must be > 0")
+    cfg = good(); cfg.precision = 7
+    rejected(cfg, b"bad precision")
+    cfg = good(); cfg.n_vehicles = 3
+    rejected(cfg, b"n_vehicles")
+    cfg = good(); cfg.max_capsules = 1000
+    rejected(cfg, b"max_capsules")
+    cfg = good(); cfg.max_spheres = -1
+    rejected(cfg, b"max_spheres")
+    cfg = good(); cfg.n_v = 0
+    rejected(cfg, b"bad ray fan")
+    cfg = good(); cfg.n_v, cfg.n_h = 1000, 1000
+    rejected(cfg, b"bad ray fan")
+    cfg = good(); cfg.blocksize_reduce = 0
+    rejected(cfg, b"blocksize_reduce")
+    cfg = good(); cfg.reward_set = 3
+    rejected(cfg, b"reward_set")
+    cfg = good(); cfg.t_step_size = 0.0
+    rejected(cfg, b"t_step_size")
+    cfg = good()   # everything valid but the ray table: still no device call
+    rejected(cfg, b"ray_table is NULL")
+    # null arguments
+    h = C.c_void_p()
+    assert lib.dockauv_create(None, 0, C.byref(h)) == -1 and b"null argument" in lib.dockauv_last_error(None)
