@@ -150,3 +150,38 @@ def test_empty_batch_and_bad_shapes_rejected_before_any_device_call(lib):
     # null arguments
     h = C.c_void_p()
     assert lib.dockauv_create(None, 0, C.byref(h)) == -1 and b"null argument" in lib.dockauv_last_error(None)
+
+
+def test_every_entry_point_refuses_a_null_handle(lib):
+    """No entry point dereferences a NULL handle: each hands back DOCKAUV_E_INVALID (-1) -- destroy / free / close of nothing
+    are no-ops (0) -- without touching a device."""
+    from gym_dockauv_amd import _capi
+    io = _capi.StepIO()
+    d = C.c_double()
+    invalid = {
+        "n_obs": lambda: lib.dockauv_n_obs(None),
+        "threads_per_group": lambda: lib.dockauv_threads_per_group(None),
+        "n_rays": lambda: lib.dockauv_n_rays(None),
+        "n_u": lambda: lib.dockauv_n_u(None),
+        "field_width": lambda: lib.dockauv_field_width(None, 0),
+        "set_field": lambda: lib.dockauv_set_field(None, 0, 0, 1, None),
+        "get_field": lambda: lib.dockauv_get_field(None, 0, 0, 1, None),
+        "reset_envs": lambda: lib.dockauv_reset_envs(None, 0, 1),
+        "step": lambda: lib.dockauv_step(None, C.byref(io), None),
+        "step (null io)": lambda: lib.dockauv_step(None, None, None),
+        "step_sequence": lambda: lib.dockauv_step_sequence(None, C.byref(io), 1, None),
+        "set_option": lambda: lib.dockauv_set_option(None, 1, 1),
+        "step_host": lambda: lib.dockauv_step_host(None, C.byref(io)),
+        "synchronize": lambda: lib.dockauv_synchronize(None),
+        "poll_status": lambda: lib.dockauv_poll_status(None),
+        "trace_enable": lambda: lib.dockauv_trace_enable(None, None, 0, 0),
+        "trace_steps": lambda: lib.dockauv_trace_steps(None),
+        "trace_read": lambda: lib.dockauv_trace_read(None, 0, 1, *([None] * 8)),
+        "time_steps": lambda: lib.dockauv_time_steps(None, C.byref(io), None, 1, C.byref(d)),
+        "step_gather_sequence": lambda: lib.dockauv_step_gather_sequence(None, C.byref(io), 1, None, 0, 0, 0, None, None),
+    }
+    for name, call in invalid.items():
+        assert call() == -1, name
+    for name, call in {"destroy": lambda: lib.dockauv_destroy(None), "p2p_free": lambda: lib.dockauv_p2p_free(None),
+                       "p2p_close": lambda: lib.dockauv_p2p_close(None)}.items():
+        assert call() == 0, name
