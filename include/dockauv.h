@@ -247,7 +247,9 @@ int dockauv_poll_status(dockauv_handle h);
  * started from, the new state, _state_dot, the filtered input u, nu_c (body frame, first three), the observation
  * BEFORE any auto-reset zeroing, the 13 reward terms and the condition bits.  Row of step k: k % capacity.
  * dockauv_trace_enable(h, env_ids, n_rows, capacity): env_ids host array, strictly increasing; n_rows = 0 switches
- *   the trace off and frees the ring.  The step counter restarts at 0.
+ *   the trace off and frees the ring.  The step counter restarts at 0.  Every call first releases the ring of an earlier
+ *   enable -- also a call that is then refused (DOCKAUV_E_INVALID: no ids / capacity < 1; DOCKAUV_E_RANGE: ids not strictly
+ *   increasing inside [0, n_envs)): after a refused call the trace is off.
  * dockauv_trace_steps(h): steps recorded since enable (or a negative error code).
  * dockauv_trace_read(h, first_step, n_steps, ...): copies steps [first_step, first_step + n_steps) -- they must still be
  *   in the ring -- to host arrays [n_steps][n_rows][width] (float64, obs float32, conditions uint8); any of the output
