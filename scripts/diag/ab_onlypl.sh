@@ -1,3 +1,10 @@
+#!/bin/bash
+# Same-box A/B of product ray kernels compiled with ONE pass form only (record: profiles/r4/ab_same_box.txt).  The variant libraries are
+# not built from the tree as it is: in dockauv_step.hip.inc's ray stage replace the dispatch
+#     if (pad_log2 == 6) run_passes(IntC<6>{}); else if (!LOG || pad_log2 == 4) run_passes(IntC<4>{}); ...
+# by `if (!LOG && ONLY_PL == 4) run_passes(IntC<4>{}); else if (!LOG && ONLY_PL == 6) run_passes(IntC<6>{}); else ...` and build
+#     scripts/build_variant.py xpl4 -DONLY_PL=4      (run on config 3: 16-beam fan)
+#     scripts/build_variant.py xpl6 -DONLY_PL=6      (run on configs 4 / 5: 63-ray fan)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4
 one() {  # lib config extra
